@@ -1,0 +1,87 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's
+ * k-mer counting path. Nothing under sh-assembly_amd/ may include, link or call
+ * this. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Pinning: the reference ships no tests or golden vectors. The filter core and
+ * ntHash are pinned against the reference's own code compiled from
+ * /root/reference (oracle/_ref, see ref_driver.cpp) and against fixtures that
+ * build generated (tests/golden/). The FASTQ chunker, reads_to_kmers and the
+ * t = 1 deNoise schedule restate cqf/CQF_mt.h, which cannot be compiled here
+ * (needs boost): for those pieces parity is pinned only through the restated
+ * driver in ref_driver.cpp running on top of the real filter.
+ */
+#ifndef CQF_ORACLE_H
+#define CQF_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_BLOCK_BYTES 89 /* 1 + 3*8 + 64, gqf.c:63-86 at bits_per_slot = 8 */
+
+typedef struct orc_qf {
+  uint64_t qb, hb;
+  uint64_t nslots, xnslots, nblocks, size;
+  uint32_t seed;
+  uint8_t *blocks;    /* nblocks*89 bytes (+ one zero guard block) */
+  uint64_t nelts;     /* runtime->nelts      cqf/CQF_mt.h:278 */
+  uint64_t ndistinct; /* runtime->ndistinct  cqf/CQF_mt.h:277 */
+  int full;           /* set when an insert would pass xnslots (the reference does not detect this) */
+} orc_qf;
+
+/* ntHash, base/nthash.hpp:295-309 */
+void orc_nthash(const char *seq, unsigned k, uint64_t *fh, uint64_t *rh);
+void orc_nthash_roll(unsigned char out, unsigned char in, unsigned k, uint64_t *fh, uint64_t *rh);
+
+/* filter, cqf/gqf.c */
+orc_qf *orc_qf_new(uint64_t qb, uint64_t hb, uint32_t seed);           /* qf_init :2187 */
+void orc_qf_free(orc_qf *qf);
+int orc_qf_insert(orc_qf *qf, uint64_t key, uint64_t count);           /* qf_insert_advance :2432; returns isNew */
+uint64_t orc_qf_count(const orc_qf *qf, uint64_t key);                 /* qf_count_key_value :2442 */
+int orc_qf_count_set_traveled(orc_qf *qf, uint64_t key, uint64_t *count); /* :3092 */
+int orc_qf_count_is_traveled(const orc_qf *qf, uint64_t key, uint64_t *count); /* :3132 */
+uint64_t orc_find_first_empty_slot(const orc_qf *qf, uint64_t from);   /* :738 */
+uint64_t orc_find_first_nonempty_slot(const orc_qf *qf, uint64_t from);/* :751 */
+uint64_t orc_qf_dump(const orc_qf *qf, uint64_t *keys, uint64_t *counts, uint64_t cap); /* iterator :2474-2601 */
+int orc_encode_counter(uint64_t remainder, uint64_t counter, uint64_t *out); /* :1225 */
+int orc_qf_check_offset(const orc_qf *qf);                             /* :3056 */
+uint64_t orc_denoise_round_t1(orc_qf *qf, uint64_t min_len);           /* CQF_mt.h:884-901, 999-1039; gqf.c:2792-3040 */
+int orc_qf_serialize(const orc_qf *qf, const char *path);              /* :2379 */
+orc_qf *orc_qf_load(const char *path);                                 /* :2396 */
+const uint8_t *orc_qf_blocks(const orc_qf *qf);
+uint64_t orc_qf_size(const orc_qf *qf);
+uint64_t orc_qf_nelts(const orc_qf *qf);
+uint64_t orc_qf_ndistinct(const orc_qf *qf);
+int orc_qf_full(const orc_qf *qf);
+void orc_qf_header(const orc_qf *qf, uint8_t out[128]);                /* qfmetadata image, gqf.h:62-77 */
+
+/* driver layer, cqf/CQF_mt.h */
+void orc_reads_to_kmers(orc_qf *qf, const char *chunk, uint64_t size, unsigned k); /* :610-731 */
+uint64_t orc_chunk_sizes(const char *path, uint64_t part_size, uint32_t overhead,
+                         uint64_t *sizes, uint64_t cap);               /* :735-816 */
+void orc_build_t1(orc_qf *qf, const char **files, int nfiles, unsigned k,
+                  uint64_t ndistinct_for_denoise, uint32_t num_denoise, int end_denoise,
+                  uint64_t part_size, uint32_t overhead, uint64_t min_denoise_len,
+                  uint64_t *stats);                                    /* :821-931, 959-995 */
+/* keys a chunk produces, in reference order (for key-stream parity of the GPU hash kernel) */
+uint64_t orc_chunk_keys(const char *chunk, uint64_t size, unsigned k, uint64_t hb,
+                        uint64_t *keys, uint64_t cap);
+
+/* sizing, src/CQF-deNoise.cpp:96-161 */
+typedef struct orc_sizing {
+  uint64_t num_true_kmers, num_false_kmers;
+  uint64_t qb, hb;
+  int num_denoise;
+  uint64_t ndistinct_for_denoise;
+  int lower_bound, upper_bound;
+} orc_sizing;
+int orc_mean_cdf2denoise(double mean, double cdf_desired);             /* CQF_mt.h:94-133 */
+double orc_true2false_dp(const double *base_errors, size_t seq_len, size_t K); /* true2falseKmer_DP.cpp:12-50 */
+void orc_size_filter(int K, uint64_t n_true, uint64_t N_total, double alpha, double true2false,
+                     int num_denoise_opt, double fr, orc_sizing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""ctypes bindings for the two CPU checkers (test infrastructure):
+
+  Oracle  -> oracle/liboracle.so       (this repo's plain-C restatement, prefix orc_)
+  Ref     -> oracle/_ref/libshk_ref.so (the real reference gqf.c + nthash.hpp, prefix ref_)
+
+Both expose the same calls so a test can run the same scenario through either.
+"""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libshk_ref.so")
+SEED = 2038074761  # src/CQF-deNoise.cpp:83
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")],
+                          stdout=subprocess.DEVNULL)
+
+
+class _QF:
+    def __init__(self, lib, prefix, handle):
+        self.L, self.p, self.h = lib, prefix, handle
+
+    def _f(self, name):
+        return getattr(self.L, self.p + name)
+
+    def insert(self, key, count=1):
+        return self._f("qf_insert")(self.h, key, count)
+
+    def count(self, key):
+        return self._f("qf_count")(self.h, key)
+
+    def count_set_traveled(self, key):
+        c = C.c_uint64(0)
+        t = self._f("qf_count_set_traveled")(self.h, key, C.byref(c))
+        return t, c.value
+
+    def count_is_traveled(self, key):
+        c = C.c_uint64(0)
+        t = self._f("qf_count_is_traveled")(self.h, key, C.byref(c))
+        return t, c.value
+
+    def blocks(self):
+        return C.string_at(self._f("qf_blocks")(self.h), self._f("qf_size")(self.h))
+
+    def nelts(self):
+        return self._f("qf_nelts")(self.h)
+
+    def ndistinct(self):
+        return self._f("qf_ndistinct")(self.h)
+
+    def check_offset(self):
+        return bool(self._f("qf_check_offset")(self.h))
+
+    def denoise_round(self, min_len=1 << 20):
+        return self._f("denoise_round_t1")(self.h, min_len)
+
+    def dump(self):
+        n = self._f("qf_dump")(self.h, None, None, 0)
+        k = (C.c_uint64 * max(n, 1))()
+        c = (C.c_uint64 * max(n, 1))()
+        self._f("qf_dump")(self.h, k, c, n)
+        return [(k[i], c[i]) for i in range(n)]
+
+    def serialize(self, path):
+        self._f("qf_serialize")(self.h, path.encode())
+
+    def reads_to_kmers(self, chunk: bytes, k):
+        self._f("reads_to_kmers")(self.h, chunk, len(chunk), k)
+
+    def find_first_empty_slot(self, frm):
+        return getattr(self.L, self.p + "find_first_empty_slot")(self.h, frm)
+
+    def find_first_nonempty_slot(self, frm):
+        return getattr(self.L, self.p + "find_first_nonempty_slot")(self.h, frm)
+
+    def build_t1(self, files, k, trigger, num_denoise, end_denoise=False,
+                 part_size=1 << 23, overhead=65535, min_len=1 << 20):
+        arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+        st = (C.c_uint64 * 3)()
+        self._f("build_t1")(self.h, arr, len(files), k, trigger, num_denoise,
+                            1 if end_denoise else 0, part_size, overhead, min_len, st)
+        return {"rounds": st[0], "removed": st[1], "chunks": st[2]}
+
+    def full(self):
+        return bool(self.L.orc_qf_full(self.h)) if self.p == "orc_" else False
+
+    def free(self):
+        if self.h:
+            self._f("qf_free")(self.h)
+            self.h = None
+
+
+class _Lib:
+    def __init__(self, path, prefix):
+        self.L = C.CDLL(path)
+        self.p = prefix
+        L, p = self.L, prefix
+        u64, vp, i32, u32 = C.c_uint64, C.c_void_p, C.c_int, C.c_uint32
+
+        def sig(name, res, args):
+            f = getattr(L, p + name)
+            f.restype, f.argtypes = res, args
+
+        sig("nthash", None, [C.c_char_p, C.c_uint, C.POINTER(u64), C.POINTER(u64)])
+        sig("nthash_roll", None, [C.c_ubyte, C.c_ubyte, C.c_uint, C.POINTER(u64), C.POINTER(u64)])
+        sig("qf_new", vp, [u64, u64, u32])
+        sig("qf_free", None, [vp])
+        sig("qf_insert", i32, [vp, u64, u64])
+        sig("qf_count", u64, [vp, u64])
+        sig("qf_count_set_traveled", i32, [vp, u64, C.POINTER(u64)])
+        sig("qf_count_is_traveled", i32, [vp, u64, C.POINTER(u64)])
+        sig("qf_blocks", vp, [vp])
+        sig("qf_size", u64, [vp])
+        sig("qf_nelts", u64, [vp])
+        sig("qf_ndistinct", u64, [vp])
+        sig("qf_check_offset", i32, [vp])
+        sig("denoise_round_t1", u64, [vp, u64])
+        sig("qf_dump", u64, [vp, C.POINTER(u64), C.POINTER(u64), u64])
+        sig("qf_serialize", None if p == "ref_" else i32, [vp, C.c_char_p])
+        sig("qf_load", vp, [C.c_char_p])
+        sig("reads_to_kmers", None, [vp, C.c_char_p, u64, C.c_uint])
+        sig("find_first_empty_slot", u64, [vp, u64])
+        sig("find_first_nonempty_slot", u64, [vp, u64])
+        sig("chunk_sizes", u64, [C.c_char_p, u64, u32, C.POINTER(u64), u64])
+        sig("build_t1", None, [vp, C.POINTER(C.c_char_p), i32, C.c_uint, u64, u32, i32,
+                               u64, u32, u64, C.POINTER(u64)])
+        if p == "ref_":
+            sig("encode_counter", i32, [vp, u64, u64, C.POINTER(u64)])
+        else:
+            sig("encode_counter", i32, [u64, u64, C.POINTER(u64)])
+            sig("chunk_keys", u64, [C.c_char_p, u64, C.c_uint, u64, C.POINTER(u64), u64])
+            sig("mean_cdf2denoise", i32, [C.c_double, C.c_double])
+            sig("qf_header", None, [vp, C.c_char_p])
+            sig("qf_full", i32, [vp])
+
+    def new(self, qb, hb=None, seed=SEED):
+        h = getattr(self.L, self.p + "qf_new")(qb, hb if hb is not None else qb + 8, seed)
+        return _QF(self.L, self.p, h)
+
+    def load(self, path):
+        return _QF(self.L, self.p, getattr(self.L, self.p + "qf_load")(path.encode()))
+
+    def nthash(self, seq: bytes, k):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        getattr(self.L, self.p + "nthash")(seq, k, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def nthash_roll(self, out, inn, k, fh, rh):
+        a, b = C.c_uint64(fh), C.c_uint64(rh)
+        getattr(self.L, self.p + "nthash_roll")(out, inn, k, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def chunk_sizes(self, path, part_size=1 << 23, overhead=65535):
+        n = getattr(self.L, self.p + "chunk_sizes")(path.encode(), part_size, overhead, None, 0)
+        arr = (C.c_uint64 * max(n, 1))()
+        getattr(self.L, self.p + "chunk_sizes")(path.encode(), part_size, overhead, arr, n)
+        return [arr[i] for i in range(n)]
+
+    def encode_counter(self, rem, count, qf=None):
+        out = (C.c_uint64 * 70)()
+        if self.p == "ref_":
+            n = self.L.ref_encode_counter(qf.h, rem, count, out)
+        else:
+            n = self.L.orc_encode_counter(rem, count, out)
+        return [out[i] for i in range(n)]
+
+    def chunk_keys(self, chunk: bytes, k, hb):
+        assert self.p == "orc_"
+        n = self.L.orc_chunk_keys(chunk, len(chunk), k, hb, None, 0)
+        arr = (C.c_uint64 * max(n, 1))()
+        self.L.orc_chunk_keys(chunk, len(chunk), k, hb, arr, n)
+        return [arr[i] for i in range(n)]
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        _oracle = _Lib(ORACLE_SO, "orc_")
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = _Lib(REF_SO, "ref_")
+    return _ref

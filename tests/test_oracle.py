@@ -1,0 +1,218 @@
+"""CPU tests: the plain-C oracle (oracle/cqf_oracle.c) against
+ (a) the golden fixtures generated from the real reference code (tests/golden/), and
+ (b) the real reference itself (oracle/_ref) when that build is present.
+Also pins the two facts the GPU design rests on:
+  * the filter's bytes are a function of the key multiset only (canonical layout);
+  * one deNoise round keeps count>=2 entries plus the range-end singletons the
+    reference's walk skips.
+"""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import cqflibs
+from cqf_canon import build_blocks, denoise_survivors
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+O = cqflibs.oracle()
+needs_ref = pytest.mark.skipif(not cqflibs.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def test_nthash_golden():
+    for kat in json.load(open(os.path.join(G, "nthash_kat.json"))):
+        s = kat["seq"].encode("latin1")
+        k = kat["k"]
+        fh, rh = O.nthash(s, k)
+        assert (fh, rh) == (kat["fh"], kat["rh"])
+        for i, (f, r) in zip(range(k, len(s)), kat["rolls"]):
+            fh, rh = O.nthash_roll(s[i - k], s[i], k, fh, rh)
+            assert (fh, rh) == (f, r)
+            assert O.nthash(s[i - k + 1:i + 1], k) == (f, r)
+
+
+def test_counter_codec_golden():
+    from cqf_canon import encode_counter
+    for row in json.load(open(os.path.join(G, "counter_codec.json"))):
+        assert O.encode_counter(row["rem"], row["count"]) == row["slots"]
+        assert encode_counter(row["rem"], row["count"]) == row["slots"]
+
+
+def test_insert_scenarios_golden():
+    for sc in json.load(open(os.path.join(G, "insert_scenarios.json"))):
+        qb = sc["qb"]
+        q = O.new(qb)
+        cnt = {}
+        for (key, c), isnew in zip(sc["ops"], sc["isnew"]):
+            assert q.insert(key, c) == isnew
+            cnt[key] = cnt.get(key, 0) + c
+        b = q.blocks()
+        assert sha(b) == sc["blocks_sha256"]
+        if sc["blocks_hex"]:
+            assert b.hex() == sc["blocks_hex"]
+        assert b == build_blocks(qb, qb + 8, cnt)  # canonical in the multiset
+        assert [q.count(k) for k in sc["probe"]] == sc["counts"]
+        assert [q.find_first_empty_slot(x) for x in range(0, 1 << qb, 13)] == sc["ffe"]
+        assert [q.find_first_nonempty_slot(x) for x in range(0, 1 << qb, 13)] == sc["ffn"]
+        assert q.dump() == sorted(cnt.items())
+        assert q.check_offset()
+        assert [list(q.count_set_traveled(k)) for k in sc["probe"][:40]] == sc["trav"]
+        assert [list(q.count_set_traveled(k)) for k in sc["probe"][:40]] == sc["trav2"]
+        assert sha(q.blocks()) == sc["blocks_trav_sha256"]
+        q.free()
+        q = O.new(qb)
+        for key, c in cnt.items():  # different insertion order and grouping: same bytes
+            q.insert(key, c)
+        assert q.blocks() == b
+        assert q.denoise_round(sc["min_len"]) == sc["removed"]
+        assert (q.nelts(), q.ndistinct()) == (sc["nelts_after"], sc["ndistinct_after"])
+        assert sha(q.blocks()) == sc["blocks_after_sha256"]
+        surv = denoise_survivors(qb, cnt, sc["min_len"])
+        assert q.blocks() == build_blocks(qb, qb + 8, surv)
+        q.free()
+
+
+def test_fastq_builds_golden(tmp_path):
+    fx = json.load(open(os.path.join(G, "fastq_builds.json")))
+    for key, sizes in fx["chunks"].items():
+        f, ps, ov = key.split(":")
+        assert O.chunk_sizes(os.path.join(G, f), int(ps), int(ov)) == sizes
+    for b in fx["builds"]:
+        c = b["cfg"]
+        q = O.new(c["qb"])
+        st = q.build_t1([os.path.join(G, f) for f in c["files"]], c["k"], c["trigger"], c["nd"], c["end"],
+                        part_size=c["ps"], overhead=c["ov"], min_len=c["ml"])
+        assert not q.full()
+        assert st == b["stats"]
+        assert (q.nelts(), q.ndistinct()) == (b["nelts"], b["ndistinct"])
+        p = str(tmp_path / "o.cqf")
+        q.serialize(p)
+        data = open(p, "rb").read()
+        assert sha(data) == b["sha256"]
+        assert data == open(os.path.join(G, b["cqf"]), "rb").read()
+        q2 = O.load(p)
+        assert q2.blocks() == q.blocks() and q2.nelts() == q.nelts()
+        q.free()
+        q2.free()
+
+
+def test_chunk_keys_match_reads_to_kmers():
+    """orc_chunk_keys (the key stream the GPU hash kernel is checked against) is the
+    same walk as orc_reads_to_kmers"""
+    data = open(os.path.join(G, "reads0.fq"), "rb").read()
+    for k, qb in ((28, 17), (47, 17)):
+        keys = O.chunk_keys(data, k, qb + 8)
+        q = O.new(qb)
+        q.reads_to_kmers(data, k)
+        cnt = {}
+        for x in keys:
+            cnt[x] = cnt.get(x, 0) + 1
+        assert q.dump() == sorted(cnt.items())
+        assert q.nelts() == len(keys)
+        q.free()
+
+
+def test_sizing_celegans():
+    """src/CQF-deNoise.cpp:96-161 on the README example (README.md:98). boost's Poisson
+    CDF is restated, so the round count is pinned only to +-1."""
+    import ctypes as C
+
+    class S(C.Structure):
+        _fields_ = [("num_true", C.c_uint64), ("num_false", C.c_uint64), ("qb", C.c_uint64), ("hb", C.c_uint64),
+                    ("nd", C.c_int), ("trigger", C.c_uint64), ("lb", C.c_int), ("ub", C.c_int)]
+    s = S()
+    O.L.orc_size_filter.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_double,
+                                    C.POINTER(S)]
+    O.L.orc_size_filter(47, 119157843, 16506371070, 0.00234, 0.0, -1, 0.0, C.byref(s))
+    assert (s.qb, s.hb) == (29, 37)
+    assert 6 <= s.nd <= 10
+    assert s.trigger == 119157843 + s.num_false // (s.nd + 1)
+
+
+@needs_ref
+def test_oracle_vs_reference_random():
+    R = cqflibs.ref()
+    rnd = random.Random(6)
+    for trial in range(40):
+        qb = rnd.choice([6, 8, 9, 11])  # even qb >= 10: the reference reads past its table in deNoise
+        load = rnd.choice([0.2, 0.5, 0.85])
+        ins = []
+        tot = {}
+        for _ in range(int((1 << qb) * load)):
+            key = (rnd.randrange(1 << qb) << 8) | rnd.choice([0, 1, 0x7f, 0x80, 0x81, 0xff, rnd.randrange(256)])
+            c = rnd.choice([1, 1, 1, 2, 3, 130, 16385])
+            ins.append((key, c))
+            tot[key] = tot.get(key, 0) + c
+        try:
+            canon = build_blocks(qb, qb + 8, tot)
+        except OverflowError:
+            continue
+        o, r = O.new(qb), R.new(qb)
+        for key, c in ins:
+            assert o.insert(key, c) == r.insert(key, c)
+        assert o.blocks() == r.blocks() == canon
+        for x in range(0, (1 << qb) + 50, 7):
+            assert o.find_first_empty_slot(x) == r.find_first_empty_slot(x)
+            assert o.find_first_nonempty_slot(x) == r.find_first_nonempty_slot(x)
+        for key in list(tot)[:60] + [rnd.randrange(1 << (qb + 8)) for _ in range(60)]:
+            assert o.count(key) == r.count(key) == tot.get(key, 0)
+            assert o.count_is_traveled(key) == r.count_is_traveled(key)
+            assert o.count_set_traveled(key) == r.count_set_traveled(key)
+            assert o.count_set_traveled(key) == r.count_set_traveled(key)
+        assert o.blocks() == r.blocks()
+        o.free(), r.free()
+        o, r = O.new(qb), R.new(qb)
+        for key, c in tot.items():
+            o.insert(key, c), r.insert(key, c)
+        ml = rnd.choice([1 << 20, 64, 300])
+        assert o.denoise_round(ml) == r.denoise_round(ml)
+        assert o.blocks() == r.blocks() == build_blocks(qb, qb + 8, denoise_survivors(qb, tot, ml))
+        assert (o.nelts(), o.ndistinct()) == (r.nelts(), r.ndistinct())
+        o.free(), r.free()
+
+
+@needs_ref
+def test_oracle_vs_reference_saturated_offsets():
+    """clusters long enough to saturate the 8-bit block offset at 255"""
+    R = cqflibs.ref()
+    rnd = random.Random(3)
+    done = 0
+    for trial in range(12):
+        qb = 11
+        tot = {}
+        base = rnd.randrange(0, 600)
+        for _ in range(rnd.choice([400, 600])):
+            key = ((base + rnd.randrange(0, 64)) << 8) | rnd.randrange(256)
+            tot[key] = tot.get(key, 0) + rnd.choice([1, 1, 2, 3, 200, 20000])
+        for _ in range(200):
+            key = (rnd.randrange(1 << qb) << 8) | rnd.randrange(256)
+            tot[key] = tot.get(key, 0) + rnd.choice([1, 1, 1, 2])
+        try:
+            canon = build_blocks(qb, qb + 8, tot)
+        except OverflowError:
+            continue
+        assert max(canon[b * 89] for b in range(len(canon) // 89)) == 255
+        done += 1
+        o, r = O.new(qb), R.new(qb)
+        items = list(tot.items())
+        rnd.shuffle(items)
+        for key, c in items:
+            if c <= 3:
+                for _ in range(c):
+                    assert o.insert(key, 1) == r.insert(key, 1)
+            else:
+                o.insert(key, c - 1), r.insert(key, c - 1)
+                o.insert(key, 1), r.insert(key, 1)
+        assert o.blocks() == r.blocks() == canon
+        for key, c in items[:150]:
+            assert o.count(key) == r.count(key) == c
+        assert o.denoise_round() == r.denoise_round()
+        assert o.blocks() == r.blocks() == build_blocks(qb, qb + 8, denoise_survivors(qb, tot))
+        o.free(), r.free()
+    assert done >= 4
