@@ -1,0 +1,144 @@
+/* shk.h -- C ABI of libshk.so: the MI355X-native k-mer counting path
+ * (CQF-deNoise stage of SH-assembly) as a drop-in for the reference's link-time
+ * boundary. Plain pointers and sizes only.
+ *
+ * What each entry point stands in for in the reference (/root/reference):
+ *   shk_create            CQF_mt::CQF_mt(qb,hb,t,seed) -> qf_init          cqf/CQF_mt.h:427-445, cqf/gqf.c:2187-2290
+ *                         + CQF_runtime_mt ctor (deNoise trigger/rounds)   cqf/CQF_mt.h:292-305
+ *   shk_count_chunks      per-chunk body of fastq_to_uint64kmers_prod:
+ *                         reads_to_kmers -> NTPC64 + qf_insert_advance,
+ *                         trigger test, DeNoise mode (t = 1 schedule)      cqf/CQF_mt.h:610-731, 821-931; gqf.c:2432
+ *   shk_hash_chunks       reads_to_kmers' hashing half only (multi-GPU
+ *                         routing: keys go to their owner before insert)   cqf/CQF_mt.h:630-718; base/nthash.hpp:295-309
+ *   shk_count_words       qf_insert_advance over a batch of routed keys    cqf/gqf.c:2432-2440
+ *   shk_denoise           one DeNoise phase (also --endDeNoise)            cqf/CQF_mt.h:860-914, 999-1039; gqf.c:2792-3040
+ *   shk_export_cqf        CQF_mt::save -> qf_serialize                     cqf/CQF_mt.h:521, 986-987; gqf.c:2379-2394
+ *   shk_import_cqf        CQF_mt::load -> qf_deserialize                   cqf/CQF_mt.h:514-519; gqf.c:2396-2420
+ *   shk_lookup            qf_count_key_value /
+ *                         qf_count_key_value_{is,set}_traveled             cqf/gqf.c:2442-2469, 3092-3163
+ *   shk_stats             runtime->nelts / ndistinct_elts / num_deNoise    cqf/CQF_mt.h:277-288
+ *   shk_destroy           CQF_mt::~CQF_mt -> qf_destroy                    cqf/CQF_mt.h:547-557; gqf.c:2306
+ *
+ * Errors: every call returns 0 or a negative SHK_ERR_* code; the library never exits
+ * the process (the reference perror()+exit()s, gqf.c:2244-2247) and, unlike the
+ * reference, detects a full table (SHK_ERR_TABLE_FULL) before anything is written.
+ * A context is not re-entrant; use one context per thread / per GPU.
+ */
+#ifndef SHK_H
+#define SHK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shk_ctx shk_ctx;
+
+enum {
+  SHK_OK = 0,
+  SHK_ERR_ARG = -1,          /* bad argument / unsupported geometry */
+  SHK_ERR_HIP = -2,          /* a HIP runtime call failed (no GPU, out of memory, ...) */
+  SHK_ERR_TABLE_FULL = -3,   /* runs would pass xnslots */
+  SHK_ERR_REGION = -4,       /* one 2048-quotient region exceeded the kernel's LDS image or hash */
+  SHK_ERR_CORRUPT = -5,      /* table metadata inconsistent / key outside this context's range */
+  SHK_ERR_FASTQ = -6,        /* malformed input: read longer than 65535, too many reads */
+  SHK_ERR_BATCH = -7,        /* batch larger than the capacities given at create time */
+  SHK_ERR_IO = -8
+};
+
+typedef struct shk_config {
+  uint32_t qb;                     /* log2(#slots) of the whole filter (all shards) */
+  uint32_t hb;                     /* hash bits, must be qb + 8 (src/CQF-deNoise.cpp:161) */
+  uint32_t seed;                   /* stored in the .cqf header (src/CQF-deNoise.cpp:83) */
+  uint32_t k;                      /* k-mer size, 1..191 */
+  uint64_t ndistinct_for_denoise;  /* deNoise trigger (src/CQF-deNoise.cpp:125) */
+  uint32_t num_denoise;            /* rounds available (runtime->num_deNoise) */
+  uint32_t reserved0;
+  uint64_t min_denoise_len;        /* 0 = reference value NUM_SLOTS_TO_LOCK<<4 = 1<<20 (CQF_mt.h:964) */
+  uint64_t max_batch_bytes;        /* capacity: FASTQ text bytes per shk_count_chunks call */
+  uint64_t max_batch_keys;         /* capacity: k-mers per batch */
+  uint64_t max_batch_reads;        /* capacity: reads per batch (0 = max_batch_bytes/16) */
+  int32_t device;                  /* HIP device ordinal */
+  uint32_t shard_index;            /* this context owns quotients [shard_index, shard_index+1) * 2^qb / num_shards */
+  uint32_t num_shards;             /* 0 or 1 = whole filter; otherwise a power of two */
+  uint32_t threads_per_group;      /* 0 = 256; tests may lower it */
+  uint32_t hash_groups;            /* 0 = auto; grid of the grid-stride kernels */
+  uint32_t max_level_bits;         /* 0 = 10; digit bits per partition level (tests lower it) */
+} shk_config;
+
+typedef struct shk_batch_stats {
+  uint64_t kmers;            /* k-mers presented to the filter by this call (qf_insert_advance calls) */
+  uint64_t new_distinct;     /* keys that were new when inserted (isNew) */
+  uint64_t removed;          /* entries removed by deNoise rounds fired inside this call */
+  uint32_t denoise_rounds;   /* rounds fired inside this call */
+  uint32_t chunks;           /* chunks consumed */
+} shk_batch_stats;
+
+typedef struct shk_totals {
+  uint64_t nelts;            /* runtime->nelts */
+  uint64_t ndistinct;        /* runtime->ndistinct_elts */
+  uint32_t rounds_left;      /* runtime->num_deNoise */
+  uint32_t rounds_done;
+  uint64_t nslots, xnslots, nblocks, table_bytes;  /* this context's (shard's) geometry */
+  uint64_t free_pointer;     /* first slot after the last run */
+} shk_totals;
+
+int shk_create(const shk_config *cfg, shk_ctx **out);
+void shk_destroy(shk_ctx *ctx);
+
+/* Count every k-mer of `nchunks` FASTQ chunks. chunk_off/chunk_len index into `text`
+ * (text_on_device != 0: `text` is a device pointer that stays valid until the call returns).
+ * Chunks are the units after which the reference tests its deNoise trigger; rounds fire
+ * inside the call exactly where the t = 1 reference would fire them. */
+int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
+                     const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
+                     shk_batch_stats *stats);
+
+/* Hash only: leaves `*nwords` key words (key | chunk_index << hb, reference emission
+ * order) in a context-owned device buffer `*d_words`, valid until the next call. */
+int shk_hash_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
+                    const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
+                    uint64_t **d_words, uint64_t *nwords);
+
+/* Insert key words that are already on the device (all keys must belong to this context's
+ * quotient range). nchunks = 1 + the largest chunk index present. */
+int shk_count_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords, uint32_t nchunks,
+                    shk_batch_stats *stats);
+
+/* One deNoise round now (the reference's --endDeNoise round; does not use up num_denoise). */
+int shk_denoise(shk_ctx *ctx, uint64_t *removed);
+
+int shk_stats(shk_ctx *ctx, shk_totals *out);
+/* 128-byte quotient_filter_metadata image (gqf.h:62-77) for this context */
+int shk_header(shk_ctx *ctx, uint8_t out[128]);
+/* table bytes (nblocks * 89) to host memory */
+int shk_export_blocks(shk_ctx *ctx, void *host_dst, uint64_t cap);
+/* header + blocks, byte-identical to qf_serialize */
+int shk_export_cqf(shk_ctx *ctx, const char *path);
+/* replace the table by one read from a .cqf (whole filter; num_shards must be 1) */
+int shk_import_cqf(shk_ctx *ctx, const char *path);
+int shk_import_blocks(shk_ctx *ctx, const void *host_src, uint64_t nbytes, uint64_t nelts, uint64_t ndistinct);
+
+/* mode 0: count + is_traveled, 1: count + set_traveled (returns the bit before), 2: count only.
+ * keys/counts/was_traveled are host pointers unless on_device != 0. was_traveled may be NULL. */
+int shk_lookup(shk_ctx *ctx, const uint64_t *keys, uint64_t n, int on_device, int mode,
+               uint64_t *counts, uint8_t *was_traveled);
+
+/* per-kernel device time measured with HIP events on the context's stream */
+typedef struct shk_kernel_time {
+  const char *name;
+  uint64_t launches;
+  double ms;
+} shk_kernel_time;
+int shk_profile_enable(shk_ctx *ctx, int on);
+int shk_profile_get(shk_ctx *ctx, shk_kernel_time *out, int cap);  /* returns #entries */
+int shk_profile_reset(shk_ctx *ctx);
+
+const char *shk_strerror(int code);
+/* last kernel error bits (diagnostics) */
+uint32_t shk_last_error_bits(shk_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

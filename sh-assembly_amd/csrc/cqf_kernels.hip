@@ -1,0 +1,684 @@
+// Counting-quotient-filter rebuild kernels: the GPU form of qf_insert_advance
+// (cqf/gqf.c:2432-2440 -> insert1_advance :1614-1915, insert_advance :2024-2136) and of
+// the deNoise sweep (qf_clean_singleton :2792-2876, driven by CQF_mt.h:884-901,999-1039).
+//
+// The table in HBM is the reference's own byte layout (89-byte packed qfblocks,
+// gqf.c:63-86), so export is a plain copy. One workgroup owns one region of 2048
+// quotients (32 blocks). It stages the region's old bytes in LDS, folds the batch's keys
+// for that region into an LDS hash, merges old runs and new keys per quotient, and
+// re-encodes the runs at their canonical positions (run of q starts at max(q, end of
+// previous run + 1); remainders ascending; counters per encode_counter :1225-1255).
+// Because those positions chain across regions, the work is split in three launches:
+//   k_region_merge<false>  per region: (T = slots its runs need, c = where they end if
+//                          nothing spills in), plus the new-key statistics
+//   k_region_scan          free pointer at every region start: f' = max(f + T, c)
+//   k_region_merge<true>   per region: lay the runs out from its free pointer, write table B
+// Tables A (read) and B (written) ping-pong; B is zeroed before the write pass.
+#include "shk_device.h"
+
+#define SHK_EMPTY 0xFFFFFFFFu
+
+struct ShkMergeArgs {
+  const uint8_t *tabA;
+  uint8_t *tabB;
+  const uint64_t *finA;         // [nregions+1] free pointer at each region start of A
+  const uint64_t *finB;         // same for B (write pass input)
+  const uint64_t *words;        // keys sorted by region; null when there are none
+  const uint64_t *region_base;  // [nregions+1] offsets into words
+  uint64_t nslots, xnslots, nblocks;
+  uint64_t q_lo;
+  uint32_t hb;
+  uint32_t chunk_lo, chunk_hi;    // only words whose chunk index lies in [lo, hi] take part
+  uint32_t hist_base, hist_shift; // coarse histogram of the first chunk of every NEW key
+  int denoise;                    // 1: drop entries whose count is exactly 1 (no new keys)
+  uint32_t *summary;              // [2*nregions]: T, c (relative to the region start; 0 = empty)
+  unsigned long long *counters;   // 0 new distinct, 1 occurrences added, 2 removed, 3 new before hist_base
+  unsigned long long *hist;       // [SHK_HIST_BINS]
+  uint32_t *err;
+};
+
+__device__ __forceinline__ unsigned shk_img_slot_off(unsigned p) {
+  return (p >> 6) * SHK_BLOCK_BYTES + SHK_OFF_SLOTS + (p & 63);
+}
+
+// decode_counter (gqf.c:1259-1299) on a block image; `pos` = first slot of the entry,
+// `run_end` = last slot of its run. Returns the number of slots.
+__device__ __forceinline__ unsigned shk_img_dec(const uint8_t *img, unsigned pos, unsigned run_end, unsigned *rem_out,
+                                                uint64_t *count) {
+  unsigned rem = img[shk_img_slot_off(pos)];
+  *rem_out = rem;
+  if (pos == run_end) { *count = 1; return 1; }
+  unsigned digit = img[shk_img_slot_off(pos + 1)];
+  if (digit > rem) { *count = 1; return 1; }
+  unsigned n = 1;
+  uint64_t cnt = 0;
+  if (digit == 0) { n++; digit = img[shk_img_slot_off(pos + n)]; }
+  while ((digit & 0x80) && pos + n < run_end) { cnt = cnt * 128 + (digit & 0x7f); n++; digit = img[shk_img_slot_off(pos + n)]; }
+  cnt = cnt * 128 + (digit & 0x7f);
+  *count = cnt + 1;
+  return n + 1;
+}
+
+// workgroup exclusive scan of free-pointer functions (thread order = quotient order)
+__device__ __forceinline__ ShkMP shk_block_exscan_mp(ShkMP v, ShkMP *total, long long *sa, long long *sb) {
+  const unsigned lane = shk_lane(), wave = shk_wave(), nw = blockDim.x / SHK_WAVE;
+  ShkMP incl = v;
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    ShkMP y;
+    y.a = __shfl_up(incl.a, d);
+    y.b = __shfl_up(incl.b, d);
+    if (lane >= (unsigned)d) incl = shk_mp_compose(y, incl);
+  }
+  if (lane == SHK_WAVE - 1) { sa[wave] = incl.a; sb[wave] = incl.b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ShkMP run; run.a = 0; run.b = SHK_NEG_INF;
+    for (unsigned w = 0; w < nw; w++) {
+      ShkMP cur; cur.a = sa[w]; cur.b = sb[w];
+      sa[w] = run.a; sb[w] = run.b;
+      run = shk_mp_compose(run, cur);
+    }
+    sa[SHK_MAX_WAVES] = run.a; sb[SHK_MAX_WAVES] = run.b;
+  }
+  __syncthreads();
+  ShkMP pre; pre.a = sa[wave]; pre.b = sb[wave];
+  // exclusive within the wave: inclusive of the previous lane
+  ShkMP prev;
+  prev.a = __shfl_up(incl.a, 1);
+  prev.b = __shfl_up(incl.b, 1);
+  if (lane == 0) { prev.a = 0; prev.b = SHK_NEG_INF; }
+  ShkMP res = shk_mp_compose(pre, prev);
+  total->a = sa[SHK_MAX_WAVES];
+  total->b = sb[SHK_MAX_WAVES];
+  __syncthreads();
+  return res;
+}
+
+template <bool WRITE>
+__global__ void k_region_merge(ShkMergeArgs A) {
+  __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
+  __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch
+  __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
+  __shared__ uint16_t qoff[SHK_REGION + 2];
+  __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
+  __shared__ uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
+  __shared__ uint16_t rstart[SHK_REGION];
+  __shared__ __attribute__((aligned(16))) uint8_t oimg[SHK_IMG_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t nimg[SHK_IMG_BYTES + 16];
+  __shared__ uint64_t oocc[SHK_REGION_BLOCKS];
+  __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
+  __shared__ uint32_t orrank[SHK_IMG_BLOCKS + 1];
+  __shared__ uint32_t lhist[SHK_HIST_BINS];
+  __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
+  __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
+  __shared__ uint32_t scratch32[SHK_MAX_WAVES + 1];
+  __shared__ uint32_t s_fail;
+
+  const unsigned tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t r = blockIdx.x;
+  const uint64_t q0 = (uint64_t)r * SHK_REGION;
+  const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
+  const uint32_t nown = (nq + 63) / 64;
+  const uint64_t b0 = q0 / 64;
+
+  // ---- old extent of this region in table A
+  const uint64_t fa0 = A.finA[r], fa1 = A.finA[r + 1];
+  const uint64_t olo_abs = fa0 > q0 ? fa0 : q0;
+  const bool old_any = fa1 > olo_abs;
+  const uint32_t olo = (uint32_t)(olo_abs - q0);
+  const uint32_t ohi = old_any ? (uint32_t)((fa1 - q0) > 0xFFFFFFF ? 0xFFFFFFF : (fa1 - q0)) : olo;
+  uint32_t nblk_old = old_any ? (ohi + 63) / 64 : 0;
+  if (nblk_old < nown) nblk_old = nown;
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  if (nblk_old > SHK_IMG_BLOCKS || ohi > SHK_IMG_SLOTS) {
+    if (tid == 0) {
+      atomicOr(A.err, SHK_E_OLD_EXTENT);
+      if (!WRITE) { A.summary[2 * r] = 0; A.summary[2 * r + 1] = 0; }
+    }
+    return;
+  }
+  if (b0 + nblk_old > A.nblocks) nblk_old = (uint32_t)(A.nblocks - b0);
+
+  // ---- stage the old bytes (dword copies; the region's first byte is 16-B aligned)
+  {
+    const uint32_t nbytes = nblk_old * SHK_BLOCK_BYTES;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(oimg);
+    for (uint32_t i = tid; i < (nbytes + 3) / 4; i += nthr) dst[i] = src[i];
+    for (uint32_t i = tid; i < SHK_HCAP; i += nthr) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; }
+    for (uint32_t i = tid; i < SHK_REGION; i += nthr) qcnt[i] = 0;
+    if (tid < SHK_HIST_BINS) lhist[tid] = 0;
+    if (WRITE) {
+      uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
+      for (uint32_t i = tid; i < (SHK_IMG_BYTES + 16) / 4; i += nthr) z[i] = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- fold this region's new keys into the LDS hash
+  uint64_t my_added = 0;
+  if (A.words) {
+    const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
+    const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
+    for (uint64_t i = kb + tid; i < ke; i += nthr) {
+      const uint64_t w = A.words[i];
+      const uint32_t chunk = (uint32_t)(w >> A.hb);
+      if (chunk < A.chunk_lo || chunk > A.chunk_hi) continue;
+      const uint64_t key = w & kmask;
+      const uint32_t ql = (uint32_t)((key >> 8) - A.q_lo - q0);
+      if (ql >= nq) { atomicOr(A.err, SHK_E_CORRUPT); continue; }
+      const uint32_t tag = (ql << 8) | (uint32_t)(key & 0xff);
+      const uint32_t want = tag << SHK_CHUNK_BITS;
+      uint32_t h = (tag * 2654435761u) >> (32 - 12);
+      bool placed = false;
+      for (uint32_t probe = 0; probe < SHK_HCAP; probe++) {
+        uint32_t cur = hkey[h];
+        if (cur == SHK_EMPTY) {
+          uint32_t prev = atomicCAS(&hkey[h], SHK_EMPTY, want | (SHK_MAX_CHUNKS - 1));
+          if (prev == SHK_EMPTY || (prev >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
+        } else if ((cur >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
+        h = (h + 1) & (SHK_HCAP - 1);
+      }
+      if (!placed) { atomicOr(&s_fail, SHK_E_HASH_FULL); continue; }
+      atomicMin(&hkey[h], want | chunk);
+      atomicAdd(&hcnt[h], 1u);
+      my_added++;
+    }
+  }
+  __syncthreads();
+
+  // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
+  if (tid < SHK_WAVE) {
+    // wave 0: two 64-wide prefix popcounts
+    uint64_t ow = 0;
+    if (tid < nown) ow = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_OCC);
+    if (tid < SHK_REGION_BLOCKS) oocc[tid] = ow;
+    uint32_t pc = (uint32_t)__popcll(ow);
+    uint32_t inc = shk_wave_incl_add(pc);
+    if (tid < SHK_REGION_BLOCKS) oorank[tid] = inc - pc;
+    if (tid == SHK_REGION_BLOCKS - 1) oorank[SHK_REGION_BLOCKS] = inc;
+    uint64_t rw = 0;
+    if (old_any && tid < nblk_old) {
+      rw = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_RUN);
+      const uint32_t s0 = tid * 64;
+      if (s0 + 64 <= olo || s0 >= ohi) rw = 0;
+      else {
+        if (olo > s0) rw &= ~((1ULL << (olo - s0)) - 1);
+        if (ohi < s0 + 64) rw &= ((1ULL << (ohi - s0)) - 1);
+      }
+    }
+    uint32_t rc = (uint32_t)__popcll(rw);
+    uint32_t rinc = shk_wave_incl_add(rc);
+    uint32_t rbase = rinc - rc;
+    orrank[tid] = rbase;
+    if (tid == SHK_WAVE - 1) orrank[SHK_IMG_BLOCKS] = rinc;
+    while (rw) {
+      unsigned bit = (unsigned)(__ffsll((long long)rw) - 1);
+      rw &= rw - 1;
+      if (rbase < SHK_REGION) orend[rbase] = (uint16_t)(tid * 64 + bit);
+      rbase++;
+    }
+  }
+  __syncthreads();
+  if (orrank[SHK_IMG_BLOCKS] != oorank[SHK_REGION_BLOCKS]) {
+    if (tid == 0) {
+      atomicOr(A.err, SHK_E_CORRUPT);
+      if (!WRITE) { A.summary[2 * r] = 0; A.summary[2 * r + 1] = 0; }
+    }
+    return;
+  }
+
+  // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
+  for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
+    if (hkey[h] != SHK_EMPTY) atomicAdd(&qcnt[hkey[h] >> (SHK_CHUNK_BITS + 8)], 1u);
+  __syncthreads();
+  const uint32_t per = SHK_REGION / nthr;  // consecutive quotients per thread (nthr divides 2048)
+  const uint32_t qa = tid * per;
+  {
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < per; j++) s += qcnt[qa + j];
+    uint32_t tot;
+    uint32_t ex = shk_block_exscan(s, &tot, scratch32);
+    for (uint32_t j = 0; j < per; j++) { qoff[qa + j] = (uint16_t)ex; ex += qcnt[qa + j]; }
+    if (tid == nthr - 1) qoff[SHK_REGION] = (uint16_t)ex;
+  }
+  __syncthreads();
+  for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
+    if (hkey[h] != SHK_EMPTY) {
+      uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
+      uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
+      nidx[pos] = (uint16_t)h;
+    }
+  __syncthreads();
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t q = qa + j;
+    const uint32_t a = qoff[q], b = qoff[q + 1];
+    for (uint32_t i = a + 1; i < b; i++) {  // insertion sort: runs are short
+      uint16_t x = nidx[i];
+      uint32_t rx = (hkey[x] >> SHK_CHUNK_BITS) & 0xff;
+      uint32_t k2 = i;
+      while (k2 > a && ((hkey[nidx[k2 - 1]] >> SHK_CHUNK_BITS) & 0xff) > rx) { nidx[k2] = nidx[k2 - 1]; k2--; }
+      nidx[k2] = x;
+    }
+  }
+  // (each thread sorted only its own quotients' segments: no barrier needed before it reads them)
+
+  // ---- pass over the quotients: merged run lengths (and statistics in the summary launch)
+  uint64_t my_new = 0, my_removed = 0, my_before = 0;
+  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t q = qa + j;
+    uint32_t len = 0;
+    if (q < nq) {
+      const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
+      uint32_t opos = 0, oend = 0;
+      bool ohas = false;
+      if (occ) {
+        const uint32_t jr = oorank[q >> 6] + (uint32_t)__popcll(oocc[q >> 6] & ((1ULL << (q & 63)) - 1));
+        oend = orend[jr];
+        opos = jr ? (uint32_t)orend[jr - 1] + 1 : olo;
+        if (opos < q) opos = q;
+        ohas = true;
+      }
+      uint32_t ni = qoff[q];
+      const uint32_t ne = qoff[q + 1];
+      uint32_t orem = 0, on = 0; uint64_t ocnt = 0;
+      if (ohas) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt);
+      while (ohas || ni < ne) {
+        uint32_t nrem = 256; uint32_t nh = 0;
+        if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
+        uint32_t rem; uint64_t total; bool is_new = false; bool prot = false; uint32_t mc = 0;
+        if (ohas && orem <= nrem) {
+          rem = orem; total = ocnt;
+          if (A.denoise) {
+            // protected singleton: k_denoise_marks set its traveled bit in table A
+            const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
+            prot = (oimg[tb] >> (opos & 7)) & 1;
+          }
+          if (orem == nrem) { total += hcnt[nh]; ni++; }
+          opos += on;
+          if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
+        } else {
+          rem = nrem; total = hcnt[nh]; is_new = true; mc = hkey[nh] & (SHK_MAX_CHUNKS - 1); ni++;
+        }
+        if (A.denoise && total < 2 && !prot) { my_removed++; continue; }
+        if (!WRITE && is_new) {
+          my_new++;
+          if (mc < A.hist_base) my_before++;
+          else {
+            uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
+            atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
+          }
+        }
+        len += shk_enc_len(rem, total);
+      }
+      if (len) {
+        ShkMP m; m.a = len; m.b = (long long)q + len;
+        mine = shk_mp_compose(mine, m);
+      }
+    }
+    qcnt[q] = len;
+  }
+  ShkMP tot;
+  ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
+
+  if (!WRITE) {
+    uint64_t t_added = shk_block_sum64(my_added, scratch64);
+    uint64_t t_new = shk_block_sum64(my_new, scratch64);
+    uint64_t t_removed = shk_block_sum64(my_removed, scratch64);
+    uint64_t t_before = shk_block_sum64(my_before, scratch64);
+    if (tid == 0) {
+      A.summary[2 * r] = (uint32_t)tot.a;
+      A.summary[2 * r + 1] = tot.b > 0 ? (uint32_t)tot.b : 0;
+      if (tot.a > 0xFFFF) atomicOr(A.err, SHK_E_RUN_TOO_LONG);
+      if (t_new) atomicAdd(&A.counters[0], (unsigned long long)t_new);
+      if (t_added) atomicAdd(&A.counters[1], (unsigned long long)t_added);
+      if (t_removed) atomicAdd(&A.counters[2], (unsigned long long)t_removed);
+      if (t_before) atomicAdd(&A.counters[3], (unsigned long long)t_before);
+      if (s_fail) atomicOr(A.err, s_fail);
+    }
+    if (tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
+    return;
+  }
+
+  // ================= write pass =================
+  const long long fin_rel = (long long)A.finB[r] - (long long)q0;
+  const long long fout_rel = (long long)A.finB[r + 1] - (long long)q0;
+  const uint32_t out_lo = fin_rel > 0 ? (uint32_t)fin_rel : 0;
+  const bool new_any = tot.a > 0;
+  const uint32_t out_hi = new_any ? (uint32_t)fout_rel : out_lo;
+  if (new_any && (fout_rel > SHK_IMG_SLOTS || fout_rel < 0)) {  // the scan kernel flags this too
+    if (tid == 0) atomicOr(A.err, SHK_E_NEW_EXTENT);
+    return;
+  }
+  {
+    // run starts and block offsets: walk my quotients with the running free pointer
+    long long f = shk_mp_apply(pre, fin_rel);
+    for (uint32_t j = 0; j < per; j++) {
+      const uint32_t q = qa + j;
+      if (q < nq && (q & 63) == 0) {
+        // offset = slots at the block start still owned by earlier runs (block_offset_strict,
+        // gqf.c:599-601), saturating at 255 like the reference's 8-bit field
+        long long o = f - (long long)q;
+        nimg[(q >> 6) * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+      }
+      const uint32_t len = qcnt[q];
+      if (len) {
+        long long st = f > (long long)q ? f : (long long)q;
+        rstart[q] = (uint16_t)st;
+        f = st + len;
+      }
+    }
+  }
+  __syncthreads();
+  // encode the merged runs into the new image
+  uint32_t *nimg32 = reinterpret_cast<uint32_t *>(nimg);
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t q = qa + j;
+    if (q >= nq || qcnt[q] == 0) continue;
+    const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
+    uint32_t opos = 0, oend = 0;
+    bool ohas = false;
+    if (occ) {
+      const uint32_t jr = oorank[q >> 6] + (uint32_t)__popcll(oocc[q >> 6] & ((1ULL << (q & 63)) - 1));
+      oend = orend[jr];
+      opos = jr ? (uint32_t)orend[jr - 1] + 1 : olo;
+      if (opos < q) opos = q;
+      ohas = true;
+    }
+    uint32_t ni = qoff[q];
+    const uint32_t ne = qoff[q + 1];
+    uint32_t orem = 0, on = 0; uint64_t ocnt = 0;
+    if (ohas) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt);
+    uint32_t wp = rstart[q];
+    uint8_t enc[12];
+    while (ohas || ni < ne) {
+      uint32_t nrem = 256; uint32_t nh = 0;
+      if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
+      uint32_t rem; uint64_t total; bool prot = false;
+      if (ohas && orem <= nrem) {
+        rem = orem; total = ocnt;
+        if (A.denoise) {
+          const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
+          prot = (oimg[tb] >> (opos & 7)) & 1;
+        }
+        if (orem == nrem) { total += hcnt[nh]; ni++; }
+        opos += on;
+        if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
+      } else {
+        rem = nrem; total = hcnt[nh]; ni++;
+      }
+      if (A.denoise && total < 2 && !prot) continue;
+      const unsigned n = shk_enc_write(enc, rem, total);
+      for (unsigned i = 0; i < n; i++) nimg[shk_img_slot_off(wp + i)] = enc[i];
+      wp += n;
+    }
+    const uint32_t last = wp - 1;  // runend bit on the run's last slot; occupied bit on q
+    {
+      const uint32_t bo = (last >> 6) * SHK_BLOCK_BYTES + SHK_OFF_RUN + ((last & 63) >> 3);
+      atomicOr(&nimg32[bo >> 2], 1u << (((bo & 3) << 3) + (last & 7)));
+      const uint32_t oo = (q >> 6) * SHK_BLOCK_BYTES + SHK_OFF_OCC + ((q & 63) >> 3);
+      atomicOr(&nimg32[oo >> 2], 1u << (((oo & 3) << 3) + (q & 7)));
+    }
+  }
+  __syncthreads();
+
+  // blocks past the last quotient hold only spilled runs: their offset bytes come from the
+  // final free pointer and are written by the last region's workgroup
+  if (r == gridDim.x - 1) {
+    const long long fend = (long long)A.finB[r + 1];
+    for (uint64_t b = A.nslots / 64 + tid; b < A.nblocks; b += nthr) {
+      long long o = fend - (long long)(64 * b);
+      A.tabB[b * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+  }
+
+  // ---- image -> table B. Own blocks: offset byte + occupieds. Slots and runends bytes of
+  // [out_lo, out_hi) only; the first and last runends byte may be shared with the
+  // neighbouring regions' runs, so they are OR-ed in atomically (B was zeroed).
+  uint8_t *tb = A.tabB + b0 * SHK_BLOCK_BYTES;
+  for (uint32_t i = tid; i < nown * 9; i += nthr) {
+    const uint32_t blk = i / 9, byte = i % 9;
+    tb[blk * SHK_BLOCK_BYTES + byte] = nimg[blk * SHK_BLOCK_BYTES + byte];
+  }
+  if (out_hi > out_lo) {
+    for (uint32_t p = out_lo + tid; p < out_hi; p += nthr) tb[shk_img_slot_off(p)] = nimg[shk_img_slot_off(p)];
+    const uint32_t m0 = out_lo >> 3, m1 = (out_hi - 1) >> 3;
+    for (uint32_t m = m0 + tid; m <= m1; m += nthr) {
+      const uint32_t bo = (m >> 3) * SHK_BLOCK_BYTES + SHK_OFF_RUN + (m & 7);
+      const uint8_t v = nimg[bo];
+      if (m == m0 || m == m1) {
+        if (v) {
+          uint8_t *addr = tb + bo;
+          uintptr_t ai = reinterpret_cast<uintptr_t>(addr);
+          uint32_t *w = reinterpret_cast<uint32_t *>(ai & ~(uintptr_t)3);
+          atomicOr(w, (uint32_t)v << ((ai & 3) << 3));
+        }
+      } else {
+        tb[bo] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- free pointers
+// fin[r+1] = max(fin[r] + T_r, region start + c_r). One workgroup walks all regions.
+__global__ void k_region_scan(const uint32_t *summary, uint32_t nregions, uint64_t xnslots, uint64_t *fin,
+                              uint32_t *err) {
+  __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
+  __shared__ long long carry_s;
+  if (threadIdx.x == 0) { carry_s = 0; fin[0] = 0; }
+  __syncthreads();
+  for (uint32_t base = 0; base < nregions; base += blockDim.x) {
+    const uint32_t r = base + threadIdx.x;
+    ShkMP m; m.a = 0; m.b = SHK_NEG_INF;
+    if (r < nregions) {
+      m.a = summary[2 * r];
+      const uint32_t c = summary[2 * r + 1];
+      if (c) m.b = (long long)r * SHK_REGION + c;
+    }
+    ShkMP tot;
+    ShkMP pre = shk_block_exscan_mp(m, &tot, mpa, mpb);
+    const long long carry = carry_s;
+    if (r < nregions) {
+      const long long fi = shk_mp_apply(pre, carry);
+      const long long fo = shk_mp_apply(m, fi);
+      fin[r + 1] = (uint64_t)fo;
+      if (m.a > 0 && fo - (long long)r * SHK_REGION > SHK_IMG_SLOTS) atomicOr(err, SHK_E_NEW_EXTENT);
+      if ((uint64_t)fo > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = shk_mp_apply(tot, carry);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- reference-style probes
+// The same block arithmetic as the reference (run_end gqf.c:655-704, offset_lower_bound
+// :706-718, find_first_empty_slot :738-748, find_first_nonempty_slot :751-774), reading the
+// packed table in HBM. Used by the lookup kernel and by the deNoise range walk.
+__device__ __forceinline__ uint64_t shk_g_occ(const uint8_t *t, uint64_t b) { return shk_ld64(t + b * SHK_BLOCK_BYTES + SHK_OFF_OCC); }
+__device__ __forceinline__ uint64_t shk_g_run(const uint8_t *t, uint64_t b) { return shk_ld64(t + b * SHK_BLOCK_BYTES + SHK_OFF_RUN); }
+__device__ __forceinline__ unsigned shk_g_off(const uint8_t *t, uint64_t b) { return t[b * SHK_BLOCK_BYTES]; }
+__device__ __forceinline__ unsigned shk_g_slot(const uint8_t *t, uint64_t p) {
+  return t[(p >> 6) * SHK_BLOCK_BYTES + SHK_OFF_SLOTS + (p & 63)];
+}
+__device__ __forceinline__ uint64_t shk_mask_lt(unsigned n) { return n >= 64 ? ~0ULL : ((1ULL << n) - 1); }
+
+// end slot of the last run with quotient <= q (>= q). Saturated offsets (255) are resolved
+// by walking left to a block whose offset is exact, instead of the reference's recursion.
+__device__ uint64_t shk_g_run_end(const uint8_t *t, uint64_t q) {
+  const uint64_t bi = q >> 6;
+  const unsigned off = q & 63;
+  // exact offset of block bi
+  uint64_t bb = bi;
+  while (bb > 0 && shk_g_off(t, bb) == 255) bb--;
+  // free pointer (relative count form): walk forward from bb to bi keeping the exact offset
+  uint64_t boff = shk_g_off(t, bb);
+  while (bb < bi) {
+    // offset of block bb+1 = end of last run with quotient < 64(bb+1), minus 64(bb+1), plus 1
+    const uint64_t occ = shk_g_occ(t, bb);
+    unsigned nruns = (unsigned)__popcll(occ);
+    uint64_t endpos;
+    if (nruns == 0) {
+      endpos = boff ? 64 * bb + boff - 1 : 0;
+      uint64_t nb = 64 * (bb + 1);
+      boff = (boff && endpos + 1 > nb) ? endpos + 1 - nb : 0;
+    } else {
+      // find the nruns-th runend at or after slot 64*bb + boff
+      uint64_t rb = bb + boff / 64;
+      unsigned ignore = boff % 64;
+      unsigned rank = nruns - 1;
+      for (;;) {
+        uint64_t w = shk_g_run(t, rb) & ~shk_mask_lt(ignore);
+        unsigned c = (unsigned)__popcll(w);
+        if (rank < c) { endpos = 64 * rb + shk_select64(w, rank); break; }
+        rank -= c; rb++; ignore = 0;
+      }
+      uint64_t nb = 64 * (bb + 1);
+      boff = endpos + 1 > nb ? endpos + 1 - nb : 0;
+    }
+    bb++;
+  }
+  const unsigned rank = (unsigned)__popcll(shk_g_occ(t, bi) & shk_mask_lt(off + 1));
+  if (rank == 0) {
+    if (boff <= off) return q;
+    return 64 * bi + boff - 1;
+  }
+  uint64_t rb = bi + boff / 64;
+  unsigned ignore = boff % 64;
+  unsigned rr = rank - 1;
+  uint64_t endpos;
+  for (;;) {
+    uint64_t w = shk_g_run(t, rb) & ~shk_mask_lt(ignore);
+    unsigned c = (unsigned)__popcll(w);
+    if (rr < c) { endpos = 64 * rb + shk_select64(w, rr); break; }
+    rr -= c; rb++; ignore = 0;
+  }
+  return endpos < q ? q : endpos;
+}
+
+__device__ __forceinline__ int shk_g_offset_lower_bound(const uint8_t *t, uint64_t slot) {
+  const uint64_t b = slot >> 6;
+  const unsigned so = slot & 63;
+  const unsigned boff = shk_g_off(t, b);
+  const uint64_t occ = shk_g_occ(t, b) & shk_mask_lt(so + 1);
+  if (boff <= so) {
+    const uint64_t re = (shk_g_run(t, b) & shk_mask_lt(so)) >> boff;
+    return __popcll(occ) - __popcll(re);
+  }
+  return (int)(boff - so) + __popcll(occ);
+}
+__device__ uint64_t shk_g_first_empty(const uint8_t *t, uint64_t from, uint64_t nblocks) {
+  for (;;) {
+    if ((from >> 6) >= nblocks) return from;  // memory past the table reads as zero
+    int lb = shk_g_offset_lower_bound(t, from);
+    if (lb == 0) return from;
+    from += lb;
+  }
+}
+__device__ uint64_t shk_g_first_nonempty(const uint8_t *t, uint64_t from, uint64_t nblocks, uint64_t xnslots) {
+  uint64_t b = from >> 6;
+  if (b >= nblocks) return xnslots;
+  uint64_t w = shk_g_occ(t, b) & ~shk_mask_lt(from & 63);
+  while (!w) {
+    b++;
+    if (b >= nblocks) return xnslots;
+    w = shk_g_occ(t, b);
+  }
+  uint64_t nx = 64 * b + (uint64_t)(__ffsll((long long)w) - 1);
+  return nx >= xnslots ? xnslots : nx;
+}
+
+// The reference's deNoise walks work ranges of >= min_len slots that end on a cluster end
+// (CQF_mt.h:888-895) and, inside a range, never visits a cluster that STARTS on the range's
+// last slot (`while(start < end_bucket_id)`, CQF_mt.h:1024, gqf.c:2881). Such a cluster is
+// a single count-1 slot; it survives the round. This kernel reproduces the walk on table A
+// and marks those slots by setting their traveled bit (zero otherwise during a build); the
+// merge kernels in denoise mode keep marked entries. One thread: the walk is a dependent chain.
+__global__ void k_denoise_marks(uint8_t *tab, uint64_t nslots, uint64_t xnslots, uint64_t nblocks, uint64_t min_len,
+                                unsigned long long *nmarked) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t cur = shk_g_first_nonempty(tab, 0, nblocks, xnslots);
+  unsigned long long marked = 0;
+  while (cur < nslots) {
+    uint64_t end = cur + min_len > nslots ? nslots : cur + min_len;
+    end = shk_g_first_empty(tab, end, nblocks) - 1;
+    // one-slot cluster exactly at `end`: slot end in use, slot end-1 empty
+    bool used = (end >> 6) < nblocks && shk_g_offset_lower_bound(tab, end) != 0;
+    bool prev_empty = end == 0 || shk_g_offset_lower_bound(tab, end - 1) == 0;
+    if (used && prev_empty) {
+      uint8_t *p = tab + (end >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((end & 63) >> 3);
+      *p = (uint8_t)(*p | (1u << (end & 7)));
+      marked++;
+    }
+    cur = shk_g_first_nonempty(tab, end + 1, nblocks, xnslots);
+  }
+  *nmarked = marked;
+}
+
+// ---------------------------------------------------------------- lookups
+// qf_count_key_value (gqf.c:2442-2469) and qf_count_key_value_set_traveled (:3092-3128):
+// one thread per query. The traveled bit belongs to the first slot of the entry; it is set
+// with a 32-bit atomic OR on the aligned word holding that bit (the reference uses a
+// plain, racy |=, gqf.c:3078).
+__global__ void k_lookup(uint8_t *tab, const uint64_t *keys, uint64_t n, uint64_t q_lo, uint64_t nslots, int mark,
+                         uint64_t *counts, uint8_t *was_traveled) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  const unsigned rem = key & 0xff;
+  const uint64_t q = (key >> 8) - q_lo;
+  uint64_t cnt = 0;
+  uint8_t trav = 0;
+  if (q < nslots && ((shk_g_occ(tab, q >> 6) >> (q & 63)) & 1)) {
+    uint64_t rs = q == 0 ? 0 : shk_g_run_end(tab, q - 1) + 1;
+    if (rs < q) rs = q;
+    for (;;) {
+      // decode_counter on the table in HBM
+      const unsigned r0 = shk_g_slot(tab, rs);
+      uint64_t c = 1, e = rs;
+      const bool re0 = (shk_g_run(tab, rs >> 6) >> (rs & 63)) & 1;
+      if (!re0) {
+        unsigned d = shk_g_slot(tab, rs + 1);
+        if (d <= r0) {
+          e = rs + 1;
+          uint64_t cc = 0;
+          if (d == 0) { e++; d = shk_g_slot(tab, e); }
+          while (d & 0x80) { cc = cc * 128 + (d & 0x7f); e++; d = shk_g_slot(tab, e); }
+          cc = cc * 128 + d;
+          c = cc + 1;
+        }
+      }
+      if (r0 == rem) {
+        cnt = c;
+        uint8_t *tp = tab + (rs >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((rs & 63) >> 3);
+        const unsigned bit = 1u << (rs & 7);
+        if (mark == 1) {
+          uintptr_t ai = reinterpret_cast<uintptr_t>(tp);
+          uint32_t *w = reinterpret_cast<uint32_t *>(ai & ~(uintptr_t)3);
+          uint32_t old = atomicOr(w, bit << ((ai & 3) << 3));
+          trav = (old >> ((ai & 3) << 3)) & bit ? 1 : 0;
+        } else if (mark == 0) {
+          trav = (*tp & bit) ? 1 : 0;
+        }
+        break;
+      }
+      if ((shk_g_run(tab, e >> 6) >> (e & 63)) & 1) break;
+      rs = e + 1;
+    }
+  }
+  counts[i] = cnt;
+  if (was_traveled) was_traveled[i] = trav;
+}
+
+// free pointer at every region start of an existing table (after shk_import): end of the
+// last run with a smaller quotient, plus one (any value <= the region start means "no spill")
+__global__ void k_build_fin(const uint8_t *tab, uint64_t nslots, uint32_t nregions, uint64_t *fin) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nregions) return;
+  uint64_t q0 = (uint64_t)r * SHK_REGION;
+  if (q0 > nslots) q0 = nslots;
+  fin[r] = q0 == 0 ? 0 : shk_g_run_end(tab, q0 - 1) + 1;
+}

@@ -1,0 +1,261 @@
+// FASTQ text -> canonical ntHash key words, on device.
+//
+// Replaces the reference's per-thread loop reads_to_kmers (cqf/CQF_mt.h:610-731) and
+// the ntHash calls it makes (base/nthash.hpp:295-309) for a whole batch of chunks:
+//   k_count_lines   newline count per chunk (4-line records, CQF_mt.h:616-726)
+//   k_scan_chunks   reads per chunk -> first read index of every chunk
+//   k_emit_reads    [start,end) of every sequence line
+//   k_count_keys    k-mers per read, honouring the reference's 'N' restart rule
+//   k_hash_reads    one wave per read: keys in exactly the reference's emission order
+//
+// ntHash without the serial roll: with j counted from the segment start,
+//   fh(p) = rol( G(p+k) ^ G(p), k-1+p ),  G(n) = XOR_{j<n} ror(seed[c_j], j)
+//   rh(p) = ror( H(p+k) ^ H(p), p ),      H(n) = XOR_{j<n} rol(seed[comp c_j], j)
+// (rotations mod 64) which is the closed form of nthash.hpp:295-309, so a wave gets
+// 64 k-mers from one 64-lane XOR scan instead of 64 dependent rolls.
+#include "shk_device.h"
+
+#define SHK_SEED_A 0x3c8bfbb395c60474ULL  // base/nthash.hpp:24-27
+#define SHK_SEED_C 0x3193c18562a02b4cULL
+#define SHK_SEED_G 0x20323ed082572324ULL
+#define SHK_SEED_T 0x295549f54be24456ULL
+#define SHK_MAX_K 191                     // ring of 256 prefix values per wave
+#define SHK_MAX_READ 65535                // a record fits the chunker's overhead (CQF_mt.h:764)
+
+// seedTab / msTab column 0 (nthash.hpp:85-153): upper and lower case map, all else is 0
+__device__ __forceinline__ uint64_t shk_seed_fwd(unsigned c) {
+  c &= 0xDF;
+  return c == 'A' ? SHK_SEED_A : c == 'C' ? SHK_SEED_C : c == 'G' ? SHK_SEED_G : c == 'T' ? SHK_SEED_T : 0ULL;
+}
+// seed of the complement base: the reference indexes with (c & cpOff), nthash.hpp:15,299
+__device__ __forceinline__ uint64_t shk_seed_rc(unsigned c) {
+  c &= 0xDF;
+  return c == 'A' ? SHK_SEED_T : c == 'C' ? SHK_SEED_G : c == 'G' ? SHK_SEED_C : c == 'T' ? SHK_SEED_A : 0ULL;
+}
+
+// exact per-byte "== '\n'" flags (0x80 in every matching byte)
+__device__ __forceinline__ uint32_t shk_nl_flags(uint32_t w) {
+  uint32_t x = w ^ 0x0A0A0A0Au;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+// Loads the 16-byte unit `u` of a chunk (units are 16-B aligned in the text buffer) and
+// returns per-word newline flags with bytes outside [off, off+len) masked away.
+__device__ __forceinline__ uint4 shk_unit_flags(const uint8_t *text, uint64_t a0, uint64_t u, uint64_t off,
+                                                uint64_t end) {
+  const uint4 v = *reinterpret_cast<const uint4 *>(text + a0 + 16 * u);
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint64_t b0 = a0 + 16 * u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t f = shk_nl_flags(w[i]);
+    uint64_t wb = b0 + 4 * i;
+    if (wb < off || wb + 4 > end) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (wb + j < off || wb + j >= end) f &= ~(0x80u << (8 * j));
+    }
+    w[i] = f;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---------------------------------------------------------------- lines per chunk
+__global__ void k_count_lines(const uint8_t *text, const uint64_t *chunk_off, const uint64_t *chunk_len,
+                              uint64_t *nlines) {
+  __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
+  const unsigned c = blockIdx.x;
+  const uint64_t off = chunk_off[c], end = off + chunk_len[c];
+  const uint64_t a0 = off & ~15ULL;
+  const uint64_t nunits = (end - a0 + 15) / 16;
+  uint64_t cnt = 0;
+  for (uint64_t u = threadIdx.x; u < nunits; u += blockDim.x) {
+    uint4 f = shk_unit_flags(text, a0, u, off, end);
+    cnt += __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);
+  }
+  uint64_t tot = shk_block_sum64(cnt, scratch);
+  if (threadIdx.x == 0) nlines[c] = tot;
+}
+
+// reads per chunk = #newlines with index 1 mod 4 = (nl+2)/4; first read index per chunk
+__global__ void k_scan_chunks(const uint64_t *nlines, unsigned nchunks, uint64_t *reads_base, uint64_t *nreads_total) {
+  __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < nchunks; base += blockDim.x) {
+    unsigned c = base + threadIdx.x;
+    uint64_t v = c < nchunks ? (nlines[c] + 2) / 4 : 0;
+    uint64_t tot;
+    uint64_t ex = shk_block_exscan64(v, &tot, scratch);
+    uint64_t carry = carry_s;
+    if (c < nchunks) reads_base[c] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    reads_base[nchunks] = carry_s;
+    *nreads_total = carry_s;
+  }
+}
+
+// ---------------------------------------------------------------- sequence-line extents
+// Line l (0-based, by newline count from the chunk start) is a header when l%4==0 and
+// the read when l%4==1 -- the same strict 4-line walk as CQF_mt.h:616-726.
+__global__ void k_emit_reads(const uint8_t *text, const uint64_t *chunk_off, const uint64_t *chunk_len,
+                             const uint64_t *reads_base, uint64_t *rd_start, uint64_t *rd_end) {
+  __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
+  __shared__ uint64_t line_carry;
+  const unsigned c = blockIdx.x;
+  const uint64_t off = chunk_off[c], end = off + chunk_len[c];
+  const uint64_t a0 = off & ~15ULL;
+  const uint64_t nunits = (end - a0 + 15) / 16;
+  const uint64_t rbase = reads_base[c], nreads = reads_base[c + 1] - rbase;
+  if (threadIdx.x == 0) line_carry = 0;
+  __syncthreads();
+  for (uint64_t ub = 0; ub < nunits; ub += blockDim.x) {
+    uint64_t u = ub + threadIdx.x;
+    uint4 f = make_uint4(0, 0, 0, 0);
+    if (u < nunits) f = shk_unit_flags(text, a0, u, off, end);
+    uint32_t n = __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);
+    uint32_t tot;
+    uint32_t ex = shk_block_exscan(n, &tot, scratch);
+    uint64_t line = line_carry + ex;
+    if (n) {
+      uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        uint32_t m = w[i];
+        while (m) {
+          int bit = __ffs(m) - 1;  // 7, 15, 23 or 31
+          m &= m - 1;
+          uint64_t pos = a0 + 16 * u + 4 * i + (bit >> 3);
+          uint64_t rd = line >> 2;
+          if (rd < nreads) {
+            if ((line & 3) == 0) rd_start[rbase + rd] = pos + 1;
+            else if ((line & 3) == 1) rd_end[rbase + rd] = pos;
+          }
+          line++;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) line_carry += tot;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- the 'N' restart rule
+// reads_to_kmers hashes the first window of a (sub)read without looking at it, then
+// restarts behind the first 'N' it meets at index >= k (CQF_mt.h:627-676). For the
+// (sub)read starting at s this returns e = index of that 'N', or len when there is none.
+// All lanes of the wave call it together; the result is wave-uniform.
+__device__ __forceinline__ uint32_t shk_segment_end(const uint8_t *rd, uint32_t len, uint32_t s, uint32_t k) {
+  const unsigned lane = shk_lane();
+  for (uint32_t base = (s + k) & ~63u; base < len; base += 64) {
+    uint32_t pos = base + lane;
+    bool isN = pos >= s + k && pos < len && rd[pos] == 'N';
+    unsigned long long m = __ballot(isN);
+    if (m) return base + (uint32_t)(__ffsll((long long)m) - 1);
+  }
+  return len;
+}
+
+// k-mers per read (one wave per read, grid-stride)
+__global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
+                             const uint64_t *nreads_p, uint32_t k, uint32_t *nkeys, uint32_t *err) {
+  const uint64_t nreads = *nreads_p;
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
+  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + shk_wave(); r < nreads; r += nwaves) {
+    const uint64_t st = rd_start[r], en = rd_end[r];
+    uint32_t cnt = 0;
+    if (en - st > SHK_MAX_READ) {
+      if (shk_lane() == 0) atomicOr(err, SHK_E_BAD_FASTQ);
+    } else {
+      const uint32_t len = (uint32_t)(en - st);
+      const uint8_t *rd = text + st;
+      uint32_t s = 0;
+      while (len >= s + k) {
+        uint32_t e = shk_segment_end(rd, len, s, k);
+        cnt += e - s - k + 1;
+        if (e == len) break;
+        s = e + 1;
+      }
+    }
+    if (shk_lane() == 0) nkeys[r] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------- hash
+// word = key | chunk << hb, key = min(fh, rh) mod 2^hb (CQF_mt.h:636-637, gqf.c:2230).
+__global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
+                             const uint64_t *nreads_p, const uint64_t *reads_base, uint32_t nchunks,
+                             uint32_t chunk_first, const uint64_t *key_base, uint32_t k, uint32_t hb,
+                             uint64_t *words, uint64_t cap, uint32_t *err) {
+  __shared__ uint64_t ringG[SHK_MAX_WAVES][256];
+  __shared__ uint64_t ringH[SHK_MAX_WAVES][256];
+  const uint64_t nreads = *nreads_p;
+  const unsigned lane = shk_lane(), wv = shk_wave();
+  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
+  const uint64_t mask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
+  uint64_t *rg = ringG[wv], *rh_ = ringH[wv];
+  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + wv; r < nreads; r += nwaves) {
+    const uint64_t st = rd_start[r], en = rd_end[r];
+    if (en - st > SHK_MAX_READ) continue;
+    const uint32_t len = (uint32_t)(en - st);
+    if (len < k) continue;
+    // chunk of this read: last c with reads_base[c] <= r (wave-uniform binary search)
+    uint32_t lo = 0, hi = nchunks;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) / 2;
+      if (reads_base[mid] <= r) lo = mid; else hi = mid;
+    }
+    const uint64_t chunk_tag = (uint64_t)(chunk_first + lo) << hb;
+    const uint8_t *rd = text + st;
+    uint64_t out = key_base[r];
+    uint32_t s = 0;
+    while (len >= s + k) {
+      const uint32_t e = shk_segment_end(rd, len, s, k);
+      const uint32_t L = e - s;             // bases in this segment
+      const uint32_t nk = L - k + 1;        // its k-mers
+      if (out + nk > cap) {
+        if (lane == 0) atomicOr(err, SHK_E_KEYS_FULL);
+        break;
+      }
+      uint64_t carryG = 0, carryH = 0;
+      if (lane == 0) { rg[0] = 0; rh_[0] = 0; }
+      for (uint32_t t = 0; t * 64 < L; t++) {
+        const uint32_t j = t * 64 + lane;   // index in the segment
+        uint64_t a = 0, c = 0;
+        if (j < L) {
+          unsigned ch = rd[s + j];
+          a = shk_ror64(shk_seed_fwd(ch), j & 63);
+          c = shk_rol64(shk_seed_rc(ch), j & 63);
+        }
+        const uint64_t G1 = shk_wave_incl_xor64(a) ^ carryG;  // G(j+1)
+        const uint64_t H1 = shk_wave_incl_xor64(c) ^ carryH;  // H(j+1)
+        carryG = __shfl(G1, SHK_WAVE - 1);
+        carryH = __shfl(H1, SHK_WAVE - 1);
+        if (j < L) { rg[(j + 1) & 255] = G1; rh_[(j + 1) & 255] = H1; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the k-mer that ends at base j starts at p = j + 1 - k
+        if (j < L && j + 1 >= k) {
+          const uint32_t p = j + 1 - k;
+          const uint64_t G0 = rg[p & 255], H0 = rh_[p & 255];
+          const uint64_t fh = shk_rol64(G1 ^ G0, (k - 1 + p) & 63);
+          const uint64_t rv = shk_ror64(H1 ^ H0, p & 63);
+          const uint64_t hv = fh < rv ? fh : rv;
+          words[out + p] = (hv & mask) | chunk_tag;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      out += nk;
+      if (e == len) break;
+      s = e + 1;
+    }
+  }
+}

@@ -1,0 +1,177 @@
+// Key-word partition by quotient region (MSD radix, one digit per level) and the
+// device-wide exclusive scan the pipeline uses.
+//
+// The reference has no such step: it takes a region lock per k-mer and shifts slots in
+// place (cqf/gqf.c:174-264, 1614-1915). Here every key of a batch is first routed to the
+// 2048-quotient region that owns it, so that one workgroup can rebuild that region in LDS
+// (cqf_kernels.hip). Order inside a region is irrelevant: the filter's bytes depend only
+// on the key multiset.
+#include "shk_device.h"
+
+#define SHK_RP_TILE 4096     // keys per window
+#define SHK_RP_MAXP 1024     // at most 10 digit bits per level
+#define SHK_SCAN_TILE 2048   // elements per workgroup in the scan kernels
+
+struct ShkRpLevel {
+  uint32_t shift;     // digit = (region >> shift) & (P-1)
+  uint32_t bits;      // P = 1 << bits
+  uint32_t nbuckets;  // buckets entering this level (= product of earlier P's)
+  uint32_t hb;
+  uint64_t q_lo;      // first quotient this context owns (multi-GPU shards)
+};
+
+__device__ __forceinline__ uint32_t shk_word_region(uint64_t w, uint32_t hb, uint64_t q_lo) {
+  uint64_t key = hb >= 64 ? w : (w & ((1ULL << hb) - 1));
+  return (uint32_t)(((key >> 8) - q_lo) >> SHK_REGION_LOG2);
+}
+
+// ---------------------------------------------------------------- exclusive scan (3 kernels)
+template <typename T>
+__global__ void k_scan_reduce(const T *in, uint64_t n_host, const uint64_t *n_dev, uint64_t *block_sums) {
+  __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
+  const uint64_t n = n_dev ? *n_dev : n_host;
+  const uint64_t base = (uint64_t)blockIdx.x * SHK_SCAN_TILE;
+  uint64_t s = 0;
+  for (uint64_t i = base + threadIdx.x; i < base + SHK_SCAN_TILE && i < n; i += blockDim.x) s += in[i];
+  uint64_t tot = shk_block_sum64(s, scratch);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+// single workgroup: exclusive scan of the block sums in place; total to *total
+__global__ void k_scan_top(uint64_t *block_sums, uint64_t nblocks, uint64_t *total) {
+  __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t b = 0; b < nblocks; b += blockDim.x) {
+    uint64_t i = b + threadIdx.x;
+    uint64_t v = i < nblocks ? block_sums[i] : 0, tot;
+    uint64_t ex = shk_block_exscan64(v, &tot, scratch);
+    uint64_t carry = carry_s;
+    if (i < nblocks) block_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+// out[i] = exclusive prefix; out[n] = total (written by the workgroup that owns index n)
+template <typename T>
+__global__ void k_scan_apply(const T *in, uint64_t n_host, const uint64_t *n_dev, const uint64_t *block_sums,
+                             const uint64_t *total, uint64_t *out) {
+  __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
+  const uint64_t n = n_dev ? *n_dev : n_host;
+  const uint64_t base = (uint64_t)blockIdx.x * SHK_SCAN_TILE;
+  if (base > n) return;
+  const unsigned per = SHK_SCAN_TILE / blockDim.x;  // blockDim.x divides the tile
+  const uint64_t my = base + (uint64_t)threadIdx.x * per;
+  uint64_t s = 0;
+  for (unsigned j = 0; j < per; j++)
+    if (my + j < n) s += in[my + j];
+  uint64_t tot;
+  uint64_t ex = shk_block_exscan64(s, &tot, scratch) + block_sums[blockIdx.x];
+  for (unsigned j = 0; j < per; j++) {
+    if (my + j < n) { out[my + j] = ex; ex += in[my + j]; }
+  }
+  if (threadIdx.x == 0 && n >= base && n < base + SHK_SCAN_TILE) out[n] = *total;
+}
+
+// ---------------------------------------------------------------- partition
+// bucket_base for level 1 = {0, n}
+__global__ void k_rp_base1(const uint64_t *n_p, uint64_t *bucket_base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { bucket_base[0] = 0; bucket_base[1] = *n_p; }
+}
+
+// first bucket that has a key in window w (windows are SHK_RP_TILE keys of the input)
+__global__ void k_rp_tile_first(const uint64_t *bucket_base, uint32_t nbuckets, const uint64_t *n_p, uint32_t *tfb) {
+  const uint64_t n = *n_p;
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t pos = w * SHK_RP_TILE;
+  if (pos >= n) return;
+  uint32_t lo = 0, hi = nbuckets;  // last b with bucket_base[b] <= pos
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) / 2;
+    if (bucket_base[mid] <= pos) lo = mid; else hi = mid;
+  }
+  tfb[w] = lo;
+}
+
+__global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint64_t *bucket_base,
+                          const uint32_t *tfb, ShkRpLevel lv, uint64_t *hist) {
+  __shared__ uint32_t lh[SHK_RP_MAXP];
+  const uint64_t n = *n_p;
+  const uint64_t wstart = (uint64_t)blockIdx.x * SHK_RP_TILE;
+  if (wstart >= n) return;
+  const uint64_t wend = wstart + SHK_RP_TILE < n ? wstart + SHK_RP_TILE : n;
+  const uint32_t P = 1u << lv.bits;
+  for (uint32_t b = tfb[blockIdx.x]; b < lv.nbuckets && bucket_base[b] < wend; b++) {
+    const uint64_t lo = bucket_base[b] > wstart ? bucket_base[b] : wstart;
+    const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
+    if (hi <= lo) continue;
+    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      uint32_t d = (shk_word_region(words[i], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+      atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
+      if (lh[d]) atomicAdd((unsigned long long *)&hist[(uint64_t)b * P + d], (unsigned long long)lh[d]);
+    __syncthreads();
+  }
+}
+
+// cursor[b*P+d] starts at the scanned base of (b,d) and is advanced by reservations
+__global__ void k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p, const uint64_t *bucket_base,
+                             const uint32_t *tfb, ShkRpLevel lv, uint64_t *cursor) {
+  __shared__ uint32_t lh[SHK_RP_MAXP];      // counts, then running rank
+  __shared__ uint32_t lbase[SHK_RP_MAXP];   // local exclusive base of each digit
+  __shared__ uint64_t gbase[SHK_RP_MAXP];   // reserved global base of each digit
+  __shared__ uint64_t stage[SHK_RP_TILE];
+  __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
+  const uint64_t n = *n_p;
+  const uint64_t wstart = (uint64_t)blockIdx.x * SHK_RP_TILE;
+  if (wstart >= n) return;
+  const uint64_t wend = wstart + SHK_RP_TILE < n ? wstart + SHK_RP_TILE : n;
+  const uint32_t P = 1u << lv.bits;
+  for (uint32_t b = tfb[blockIdx.x]; b < lv.nbuckets && bucket_base[b] < wend; b++) {
+    const uint64_t lo = bucket_base[b] > wstart ? bucket_base[b] : wstart;
+    const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
+    if (hi <= lo) continue;
+    const uint32_t cnt = (uint32_t)(hi - lo);
+    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      uint32_t d = (shk_word_region(in[lo + i], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+      atomicAdd(&lh[d], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the digit counts (P <= 1024, blockDim may be smaller)
+    uint32_t carry = 0;
+    for (uint32_t d0 = 0; d0 < P; d0 += blockDim.x) {
+      uint32_t d = d0 + threadIdx.x;
+      uint32_t v = d < P ? lh[d] : 0, tot;
+      uint32_t ex = shk_block_exscan(v, &tot, scratch);
+      if (d < P) {
+        lbase[d] = carry + ex;
+        gbase[d] = v ? atomicAdd((unsigned long long *)&cursor[(uint64_t)b * P + d], (unsigned long long)v) : 0;
+      }
+      carry += tot;
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      uint64_t w = in[lo + i];
+      uint32_t d = (shk_word_region(w, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+      uint32_t rank = atomicAdd(&lh[d], 1u);
+      stage[lbase[d] + rank] = w;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      uint64_t w = stage[i];
+      uint32_t d = (shk_word_region(w, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+      out[gbase[d] + (i - lbase[d])] = w;
+    }
+    __syncthreads();
+  }
+}

@@ -1,0 +1,660 @@
+// Host side of libshk.so: context, buffers, launch sequences. See include/shk.h for the
+// reference interface each entry point replaces. Everything here runs on one HIP stream
+// per context; the only host<->device synchronisations in a batch are the one that reads
+// the merge statistics (needed to decide where a deNoise round fires) and the final one.
+#include "../../include/shk.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "kmer_kernels.hip"
+#include "partition_kernels.hip"
+#include "cqf_kernels.hip"
+
+#define SHK_SLACK 256  // bytes of slack behind buffers read with wide loads
+
+enum {
+  KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
+};
+static const char *kp_names[KP_N] = {
+  "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
+  "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>",
+  "k_denoise_marks", "k_lookup", "misc"};
+
+struct PendingEvent { int id; hipEvent_t a, b; };
+
+struct shk_ctx {
+  shk_config cfg;
+  int dev;
+  hipStream_t stream;
+  // geometry of this context (shard)
+  uint64_t g_nslots;            // whole filter
+  uint64_t q_lo, nslots, xnslots, nblocks, table_bytes;
+  uint32_t nregions, rbits;     // regions and ceil(log2(nregions))
+  uint32_t nlevels;
+  ShkRpLevel lv[4];
+  uint32_t threads, hash_groups;
+  // state
+  uint64_t nelts, ndistinct;
+  uint32_t rounds_left, rounds_done;
+  // device buffers
+  uint8_t *tab[2];
+  uint64_t *fin[2];
+  int cur;                      // which of tab[]/fin[] is live
+  uint8_t *d_text;
+  uint64_t *d_chunk_off, *d_chunk_len, *d_nlines, *d_reads_base;
+  uint64_t *d_rd_start, *d_rd_end;
+  uint32_t *d_nkeys;
+  uint64_t *d_key_base;
+  uint64_t *d_words[2];
+  uint64_t *d_scalars;          // [0] nreads, [1] nwords, [2] scan total scratch, [3] marks
+  uint64_t *d_block_sums;
+  uint64_t *d_hist[4];          // per level: nbuckets*P
+  uint64_t *d_base[5];          // base[l]: bucket bases entering level l (base[nlevels] = region_base)
+  uint64_t *d_cursor;
+  uint32_t *d_tfb;
+  uint32_t *d_summary;
+  unsigned long long *d_counters;  // 4 counters + 32 hist bins
+  uint32_t *d_err;
+  uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
+  uint64_t max_reads;
+  // profiling
+  int prof_on;
+  double prof_ms[KP_N];
+  uint64_t prof_n[KP_N];
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> evpool;
+  uint32_t last_err_bits;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libshk: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return SHK_ERR_HIP; } } while (0)
+
+static hipEvent_t ev_get(shk_ctx *c) {
+  if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  shk_ctx *c; int id; hipEvent_t a, b;
+  ProfScope(shk_ctx *c_, int id_) : c(c_), id(id_) {
+    if (c->prof_on) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); }
+  }
+  ~ProfScope() {
+    if (c->prof_on) { hipEventRecord(b, c->stream); PendingEvent p = {id, a, b}; c->pending.push_back(p); }
+  }
+};
+static void prof_collect(shk_ctx *c) {
+  for (size_t i = 0; i < c->pending.size(); i++) {
+    float ms = 0;
+    hipEventSynchronize(c->pending[i].b);
+    hipEventElapsedTime(&ms, c->pending[i].a, c->pending[i].b);
+    c->prof_ms[c->pending[i].id] += ms;
+    c->prof_n[c->pending[i].id]++;
+    c->evpool.push_back(c->pending[i].a);
+    c->evpool.push_back(c->pending[i].b);
+  }
+  c->pending.clear();
+}
+
+static int map_err_bits(uint32_t bits) {
+  if (!bits) return SHK_OK;
+  if (bits & SHK_E_TABLE_FULL) return SHK_ERR_TABLE_FULL;
+  if (bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT | SHK_E_HASH_FULL | SHK_E_RUN_TOO_LONG)) return SHK_ERR_REGION;
+  if (bits & SHK_E_CORRUPT) return SHK_ERR_CORRUPT;
+  if (bits & SHK_E_BAD_FASTQ) return SHK_ERR_FASTQ;
+  if (bits & SHK_E_KEYS_FULL) return SHK_ERR_BATCH;
+  return SHK_ERR_CORRUPT;
+}
+
+extern "C" const char *shk_strerror(int code) {
+  switch (code) {
+    case SHK_OK: return "ok";
+    case SHK_ERR_ARG: return "bad argument or unsupported geometry";
+    case SHK_ERR_HIP: return "HIP runtime error (is a GPU present?)";
+    case SHK_ERR_TABLE_FULL: return "counting quotient filter is full";
+    case SHK_ERR_REGION: return "a 2048-quotient region exceeds the kernel's on-chip image";
+    case SHK_ERR_CORRUPT: return "table metadata inconsistent or key outside this context's range";
+    case SHK_ERR_FASTQ: return "malformed FASTQ input";
+    case SHK_ERR_BATCH: return "batch exceeds the capacities given to shk_create";
+    case SHK_ERR_IO: return "file I/O error";
+  }
+  return "unknown error";
+}
+extern "C" uint32_t shk_last_error_bits(shk_ctx *c) { return c ? c->last_err_bits : 0; }
+
+template <typename T> static int dmalloc(T **p, uint64_t n) {
+  void *v = nullptr;
+  HIPCHK(hipMalloc(&v, n * sizeof(T) + SHK_SLACK));
+  *p = (T *)v;
+  return 0;
+}
+
+// ------------------------------------------------------------------ create / destroy
+extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
+  if (!cfg || !out) return SHK_ERR_ARG;
+  if (cfg->qb < 6 || cfg->qb > 40 || cfg->hb != cfg->qb + 8 || cfg->k < 1 || cfg->k > SHK_MAX_K) return SHK_ERR_ARG;
+  uint32_t ns = cfg->num_shards ? cfg->num_shards : 1;
+  if (ns & (ns - 1)) return SHK_ERR_ARG;
+  if (cfg->shard_index >= ns) return SHK_ERR_ARG;
+  if (cfg->hb + SHK_CHUNK_BITS > 64) return SHK_ERR_ARG;
+  shk_ctx *c = new shk_ctx();
+  c->cfg = *cfg;
+  c->dev = cfg->device;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamCreate(&c->stream));
+  c->g_nslots = 1ULL << cfg->qb;
+  if (c->g_nslots / ns < 64) { delete c; return SHK_ERR_ARG; }
+  c->nslots = c->g_nslots / ns;
+  c->q_lo = c->nslots * cfg->shard_index;
+  // qf_init geometry, gqf.c:2197-2198 (every shard keeps a full-size overflow tail)
+  c->xnslots = c->nslots + (uint64_t)(10 * sqrt((double)c->g_nslots));
+  c->nblocks = (c->xnslots + 63) / 64;
+  c->table_bytes = c->nblocks * SHK_BLOCK_BYTES;
+  c->nregions = (uint32_t)((c->nslots + SHK_REGION - 1) / SHK_REGION);
+  c->rbits = 0;
+  while ((1u << c->rbits) < c->nregions) c->rbits++;
+  const uint32_t mlb = cfg->max_level_bits ? cfg->max_level_bits : 10;
+  if (mlb > 10) { delete c; return SHK_ERR_ARG; }
+  c->nlevels = (c->rbits + mlb - 1) / mlb;
+  if (c->nlevels > 4) { delete c; return SHK_ERR_ARG; }
+  {
+    uint32_t left = c->rbits, nb = 1;
+    for (uint32_t l = 0; l < c->nlevels; l++) {
+      uint32_t bits = (left + (c->nlevels - l) - 1) / (c->nlevels - l);
+      left -= bits;
+      c->lv[l].shift = left; c->lv[l].bits = bits; c->lv[l].nbuckets = nb; c->lv[l].hb = cfg->hb; c->lv[l].q_lo = c->q_lo;
+      nb <<= bits;
+    }
+  }
+  c->threads = cfg->threads_per_group ? cfg->threads_per_group : 256;
+  if (c->threads < 64 || c->threads > 1024 || (c->threads & (c->threads - 1))) { delete c; return SHK_ERR_ARG; }
+  c->hash_groups = cfg->hash_groups ? cfg->hash_groups : 2048;
+  c->rounds_left = cfg->num_denoise;
+  c->max_reads = cfg->max_batch_reads ? cfg->max_batch_reads : cfg->max_batch_bytes / 16 + 1024;
+  const uint64_t capk = cfg->max_batch_keys;
+  const uint32_t maxch = SHK_MAX_CHUNKS;
+  for (int i = 0; i < 2; i++) {
+    if (dmalloc(&c->tab[i], c->table_bytes)) return SHK_ERR_HIP;
+    if (dmalloc(&c->fin[i], (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
+    if (dmalloc(&c->d_words[i], capk + 1)) return SHK_ERR_HIP;
+  }
+  if (dmalloc(&c->d_text, cfg->max_batch_bytes + 64)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_chunk_off, maxch) || dmalloc(&c->d_chunk_len, maxch) || dmalloc(&c->d_nlines, maxch) ||
+      dmalloc(&c->d_reads_base, maxch + 1)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_rd_start, c->max_reads + 1) || dmalloc(&c->d_rd_end, c->max_reads + 1) ||
+      dmalloc(&c->d_nkeys, c->max_reads + 1) || dmalloc(&c->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_scalars, 8)) return SHK_ERR_HIP;
+  {
+    uint64_t mx = capk > c->max_reads ? capk : c->max_reads;
+    uint64_t pw = 1ULL << c->rbits;
+    if (pw > mx) mx = pw;
+    if (dmalloc(&c->d_block_sums, mx / SHK_SCAN_TILE + 4)) return SHK_ERR_HIP;
+  }
+  {
+    uint64_t nb = 1;
+    if (dmalloc(&c->d_base[0], 2)) return SHK_ERR_HIP;
+    for (uint32_t l = 0; l < c->nlevels; l++) {
+      uint64_t n = nb << c->lv[l].bits;
+      if (dmalloc(&c->d_hist[l], n + 1) || dmalloc(&c->d_base[l + 1], n + 2)) return SHK_ERR_HIP;
+      nb = n;
+    }
+    if (dmalloc(&c->d_cursor, nb + 2)) return SHK_ERR_HIP;
+  }
+  if (dmalloc(&c->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_summary, 2 * (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_counters, 4 + SHK_HIST_BINS)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_err, 4)) return SHK_ERR_HIP;
+  HIPCHK(hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipMemsetAsync(c->tab[0], 0, c->table_bytes + SHK_SLACK, c->stream));
+  HIPCHK(hipMemsetAsync(c->tab[1], 0, c->table_bytes + SHK_SLACK, c->stream));
+  HIPCHK(hipMemsetAsync(c->fin[0], 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->fin[1], 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = c;
+  return SHK_OK;
+}
+
+extern "C" void shk_destroy(shk_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->dev);
+  hipStreamSynchronize(c->stream);
+  prof_collect(c);
+  for (size_t i = 0; i < c->evpool.size(); i++) hipEventDestroy(c->evpool[i]);
+  for (int i = 0; i < 2; i++) { hipFree(c->tab[i]); hipFree(c->fin[i]); hipFree(c->d_words[i]); }
+  hipFree(c->d_text); hipFree(c->d_chunk_off); hipFree(c->d_chunk_len); hipFree(c->d_nlines); hipFree(c->d_reads_base);
+  hipFree(c->d_rd_start); hipFree(c->d_rd_end); hipFree(c->d_nkeys); hipFree(c->d_key_base); hipFree(c->d_scalars);
+  hipFree(c->d_block_sums);
+  hipFree(c->d_base[0]);
+  for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
+  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_counters); hipFree(c->d_err);
+  hipHostFree(c->h_pinned);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ------------------------------------------------------------------ helpers
+// exclusive scan of in[0..n) (n on the host, or *n_dev on the device with n_max as bound)
+template <typename T>
+static int run_scan(shk_ctx *c, const T *in, uint64_t n_max, const uint64_t *n_dev, uint64_t *out) {
+  ProfScope ps(c, KP_SCAN);
+  const uint32_t nb = (uint32_t)(n_max / SHK_SCAN_TILE + 1);
+  hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, c->d_block_sums);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(c->threads), 0, c->stream, c->d_block_sums, (uint64_t)nb, c->d_scalars + 2);
+  hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, c->d_block_sums,
+                     c->d_scalars + 2, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int fetch_err(shk_ctx *c, uint32_t *bits) {
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *bits = *(uint32_t *)(c->h_pinned + 40);
+  c->last_err_bits = *bits;
+  if (*bits) hipMemsetAsync(c->d_err, 0, 16, c->stream);
+  return 0;
+}
+
+// text + chunk table -> key words in d_words[0]; d_scalars[1] = #words
+static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first) {
+  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + nchunks > SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+  for (uint32_t i = 0; i < nchunks; i++)
+    if (chunk_off[i] + chunk_len[i] > text_bytes) return SHK_ERR_ARG;
+  const uint8_t *dtext;
+  if (on_device) dtext = (const uint8_t *)text;
+  else {
+    if (text_bytes > c->cfg.max_batch_bytes) return SHK_ERR_BATCH;
+    HIPCHK(hipMemcpyAsync(c->d_text, text, text_bytes, hipMemcpyHostToDevice, c->stream));
+    dtext = c->d_text;
+  }
+  HIPCHK(hipMemcpyAsync(c->d_chunk_off, chunk_off, nchunks * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_chunk_len, chunk_len, nchunks * 8, hipMemcpyHostToDevice, c->stream));
+  { ProfScope ps(c, KP_COUNT_LINES);
+    hipLaunchKernelGGL(k_count_lines, dim3(nchunks), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len, c->d_nlines); }
+  { ProfScope ps(c, KP_SCAN_CHUNKS);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(c->threads), 0, c->stream, c->d_nlines, nchunks, c->d_reads_base, c->d_scalars + 0); }
+  // the read arrays are sized by max_reads: the count is checked on the host below
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 41, c->d_scalars, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint64_t nreads = c->h_pinned[41];
+  if (nreads > c->max_reads) return SHK_ERR_BATCH;
+  { ProfScope ps(c, KP_EMIT_READS);
+    hipLaunchKernelGGL(k_emit_reads, dim3(nchunks), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len,
+                       c->d_reads_base, c->d_rd_start, c->d_rd_end); }
+  uint32_t groups = c->hash_groups;
+  { uint64_t need = nreads / (c->threads / SHK_WAVE) + 1; if (need < groups) groups = (uint32_t)need; }
+  { ProfScope ps(c, KP_COUNT_KEYS);
+    hipLaunchKernelGGL(k_count_keys, dim3(groups), dim3(c->threads), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
+                       c->d_scalars + 0, c->cfg.k, c->d_nkeys, c->d_err); }
+  if (run_scan<uint32_t>(c, c->d_nkeys, nreads, nullptr, c->d_key_base)) return SHK_ERR_HIP;
+  // total = key_base[nreads] -> d_scalars[1]
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->d_key_base + nreads, 8, hipMemcpyDeviceToDevice, c->stream));
+  { ProfScope ps(c, KP_HASH);
+    hipLaunchKernelGGL(k_hash_reads, dim3(groups), dim3(c->threads), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
+                       c->d_scalars + 0, c->d_reads_base, nchunks, chunk_first, c->d_key_base, c->cfg.k, c->cfg.hb,
+                       c->d_words[0], c->cfg.max_batch_keys, c->d_err); }
+  HIPCHK(hipGetLastError());
+  return SHK_OK;
+}
+
+// words in d_words[src] (count in d_scalars[1], bound nmax) -> sorted by region in
+// d_words[*dst]; region offsets in d_base[nlevels]
+static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
+  const uint64_t *n_p = c->d_scalars + 1;
+  { ProfScope ps(c, KP_RP_PREP);
+    hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]); }
+  const uint32_t nwin = (uint32_t)(nmax / SHK_RP_TILE + 1);
+  int cur = src;
+  for (uint32_t l = 0; l < c->nlevels; l++) {
+    const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
+    { ProfScope ps(c, KP_RP_PREP);
+      hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
+      HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
+    { ProfScope ps(c, KP_RP_HIST);
+      hipLaunchKernelGGL(k_rp_hist, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[cur], n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l]); }
+    if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
+    { ProfScope ps(c, KP_RP_SCATTER);
+      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[cur], c->d_words[cur ^ 1], n_p,
+                         c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor); }
+    cur ^= 1;
+  }
+  if (c->nlevels == 0) {
+    // a single region: its keys are [0, n)
+  }
+  HIPCHK(hipGetLastError());
+  *dst = cur;
+  return SHK_OK;
+}
+
+struct MergeOut {
+  uint64_t newd, added, removed, before;
+  uint64_t hist[SHK_HIST_BINS];
+  uint32_t err;
+};
+
+static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase,
+                      uint32_t hshift, int denoise) {
+  A->tabA = c->tab[c->cur]; A->tabB = c->tab[c->cur ^ 1];
+  A->finA = c->fin[c->cur]; A->finB = c->fin[c->cur ^ 1];
+  A->words = words; A->region_base = c->d_base[c->nlevels];
+  A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
+  A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
+  A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
+}
+
+// summary launch + free-pointer scan, then read the statistics back (one synchronisation)
+static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase, uint32_t hshift,
+                         int denoise, MergeOut *o) {
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, hbase, hshift, denoise);
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
+  { ProfScope ps(c, KP_MERGE_SUM);
+    hipLaunchKernelGGL((k_region_merge<false>), dim3(c->nregions), dim3(c->threads), 0, c->stream, A); }
+  { ProfScope ps(c, KP_REGION_SCAN);
+    hipLaunchKernelGGL(k_region_scan, dim3(1), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->xnslots,
+                       c->fin[c->cur ^ 1], c->d_err); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  o->newd = c->h_pinned[0]; o->added = c->h_pinned[1]; o->removed = c->h_pinned[2]; o->before = c->h_pinned[3];
+  for (int i = 0; i < SHK_HIST_BINS; i++) o->hist[i] = c->h_pinned[4 + i];
+  o->err = *(uint32_t *)(c->h_pinned + 40);
+  c->last_err_bits = o->err;
+  if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  return SHK_OK;
+}
+
+// write launch for the summary that was just computed; then flip the live table
+static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int denoise) {
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, 0, 0, denoise);
+  HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
+  { ProfScope ps(c, KP_MERGE_WRITE);
+    hipLaunchKernelGGL((k_region_merge<true>), dim3(c->nregions), dim3(c->threads), 0, c->stream, A); }
+  HIPCHK(hipGetLastError());
+  c->cur ^= 1;
+  return SHK_OK;
+}
+
+static int denoise_round(shk_ctx *c, uint64_t *removed) {
+  uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
+  { ProfScope ps(c, KP_MARKS);
+    hipLaunchKernelGGL(k_denoise_marks, dim3(1), dim3(64), 0, c->stream, c->tab[c->cur], c->nslots, c->xnslots, c->nblocks,
+                       ml, (unsigned long long *)(c->d_scalars + 3)); }
+  MergeOut o;
+  int rc = merge_summary(c, nullptr, 0, 0, 0, 0, 1, &o);
+  if (rc) return rc;
+  if (o.err) return map_err_bits(o.err);
+  rc = merge_write(c, nullptr, 0, 0, 1);
+  if (rc) return rc;
+  c->nelts -= o.removed;        // CQF_mt.h:1037-1038
+  c->ndistinct -= o.removed;
+  *removed = o.removed;
+  return SHK_OK;
+}
+
+// Insert the words of chunks [0, nchunks) (already partitioned in `words`), firing deNoise
+// rounds where the t = 1 reference would: after the first chunk at which
+// ndistinct >= trigger while rounds are left (CQF_mt.h:837, 860-869).
+static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_batch_stats *st) {
+  uint32_t lo = 0;
+  while (lo < nchunks) {
+    uint32_t hi = nchunks - 1;
+    const bool watch = c->rounds_left > 0;
+    uint32_t span = hi - lo + 1, shift = 0;
+    while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
+    MergeOut o;
+    int rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o);
+    if (rc) return rc;
+    if (o.err) return map_err_bits(o.err);
+    bool fire = false;
+    if (watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise) {
+      // locate the first chunk at which the running distinct count reaches the trigger
+      uint32_t base = lo;
+      uint64_t acc = c->ndistinct;  // distinct keys before chunk `base`
+      for (;;) {
+        uint32_t bin = 0;
+        uint64_t run = acc + o.before;
+        for (bin = 0; bin < SHK_HIST_BINS; bin++) {
+          if (run + o.hist[bin] >= c->cfg.ndistinct_for_denoise) break;
+          run += o.hist[bin];
+        }
+        if (bin == SHK_HIST_BINS) bin = SHK_HIST_BINS - 1;  // cannot happen: the total crosses
+        uint32_t b_lo = base + (bin << shift);
+        uint32_t b_hi = b_lo + (1u << shift) - 1;
+        if (b_hi > hi) b_hi = hi;
+        if (shift == 0) { hi = b_lo; break; }
+        // refine inside [b_lo, b_hi]: keys first seen before b_lo are counted in `before`
+        uint32_t span2 = b_hi - b_lo + 1;
+        shift = 0;
+        while ((span2 + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
+        base = b_lo;
+        rc = merge_summary(c, words, lo, b_hi, base, shift, 0, &o);
+        if (rc) return rc;
+        if (o.err) return map_err_bits(o.err);
+      }
+      fire = true;
+      // summary for exactly the chunks [lo, hi]
+      rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o);
+      if (rc) return rc;
+      if (o.err) return map_err_bits(o.err);
+    }
+    rc = merge_write(c, words, lo, hi, 0);
+    if (rc) return rc;
+    c->ndistinct += o.newd;
+    c->nelts += o.added;
+    st->kmers += o.added;
+    st->new_distinct += o.newd;
+    st->chunks += hi - lo + 1;
+    if (fire) {
+      uint64_t removed = 0;
+      c->rounds_left--;
+      c->rounds_done++;
+      rc = denoise_round(c, &removed);
+      if (rc) return rc;
+      st->removed += removed;
+      st->denoise_rounds++;
+    }
+    lo = hi + 1;
+  }
+  return SHK_OK;
+}
+
+static int finish(shk_ctx *c, int rc) {
+  uint32_t bits = 0;
+  int rc2 = fetch_err(c, &bits);
+  prof_collect(c);
+  if (rc) return rc;
+  if (rc2) return rc2;
+  return map_err_bits(bits);
+}
+
+extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes,
+                                const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
+                                shk_batch_stats *stats) {
+  if (!c || !text || !chunk_off || !chunk_len) return SHK_ERR_ARG;
+  shk_batch_stats st;
+  memset(&st, 0, sizeof(st));
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0);
+  if (rc) return finish(c, rc);
+  uint32_t bits = 0;
+  if (fetch_err(c, &bits)) return SHK_ERR_HIP;
+  if (bits) { prof_collect(c); return map_err_bits(bits); }
+  int dst = 0;
+  rc = partition_stage(c, 0, c->cfg.max_batch_keys, &dst);
+  if (rc) return finish(c, rc);
+  rc = merge_stage(c, c->d_words[dst], nchunks, &st);
+  if (stats) *stats = st;
+  return finish(c, rc);
+}
+
+extern "C" int shk_hash_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes,
+                               const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
+                               uint64_t **d_words, uint64_t *nwords) {
+  if (!c || !text || !d_words || !nwords) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0);
+  if (rc) return finish(c, rc);
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
+  rc = finish(c, 0);
+  *d_words = c->d_words[0];
+  *nwords = c->h_pinned[42];
+  return rc;
+}
+
+extern "C" int shk_count_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwords, uint32_t nchunks,
+                               shk_batch_stats *stats) {
+  if (!c || (!d_words && nwords) || nchunks == 0 || nchunks > SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (nwords > c->cfg.max_batch_keys) return SHK_ERR_BATCH;
+  shk_batch_stats st;
+  memset(&st, 0, sizeof(st));
+  HIPCHK(hipSetDevice(c->dev));
+  if (d_words != c->d_words[0] && nwords)
+    HIPCHK(hipMemcpyAsync(c->d_words[0], d_words, nwords * 8, hipMemcpyDeviceToDevice, c->stream));
+  c->h_pinned[43] = nwords;
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
+  int dst = 0;
+  int rc = partition_stage(c, 0, nwords, &dst);
+  if (rc) return finish(c, rc);
+  rc = merge_stage(c, c->d_words[dst], nchunks, &st);
+  if (stats) *stats = st;
+  return finish(c, rc);
+}
+
+extern "C" int shk_denoise(shk_ctx *c, uint64_t *removed) {
+  if (!c) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  uint64_t r = 0;
+  int rc = denoise_round(c, &r);
+  if (!rc) c->rounds_done++;
+  if (removed) *removed = r;
+  return finish(c, rc);
+}
+
+extern "C" int shk_stats(shk_ctx *c, shk_totals *o) {
+  if (!c || !o) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  o->nelts = c->nelts; o->ndistinct = c->ndistinct; o->rounds_left = c->rounds_left; o->rounds_done = c->rounds_done;
+  o->nslots = c->nslots; o->xnslots = c->xnslots; o->nblocks = c->nblocks; o->table_bytes = c->table_bytes;
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 44, c->fin[c->cur] + c->nregions, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  o->free_pointer = c->h_pinned[44];
+  return SHK_OK;
+}
+
+// quotient_filter_metadata, gqf.h:62-77 (field offsets checked against the compiled
+// reference: see oracle/cqf_oracle.c orc_qf_header)
+extern "C" int shk_header(shk_ctx *c, uint8_t out[128]) {
+  if (!c || !out) return SHK_ERR_ARG;
+  memset(out, 0, 128);
+  uint64_t v;
+#define PUT(off, val) do { v = (val); memcpy(out + (off), &v, 8); } while (0)
+  PUT(0, c->table_bytes);
+  memcpy(out + 8, &c->cfg.seed, 4);
+  PUT(16, c->nslots); PUT(24, c->xnslots); PUT(32, (uint64_t)c->cfg.hb); PUT(40, 0);
+  PUT(48, 8); PUT(56, 8);
+  { unsigned __int128 range = (unsigned __int128)c->nslots << 8; memcpy(out + 64, &range, 16); }
+  PUT(80, c->nblocks); PUT(88, c->nelts); PUT(96, c->ndistinct); PUT(104, 0);
+  PUT(112, c->xnslots / (1ULL << 16) + 2);
+#undef PUT
+  return SHK_OK;
+}
+
+extern "C" int shk_export_blocks(shk_ctx *c, void *dst, uint64_t cap) {
+  if (!c || !dst || cap < c->table_bytes) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(dst, c->tab[c->cur], c->table_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+extern "C" int shk_export_cqf(shk_ctx *c, const char *path) {
+  if (!c || !path) return SHK_ERR_ARG;
+  std::vector<uint8_t> buf(c->table_bytes);
+  int rc = shk_export_blocks(c, buf.data(), buf.size());
+  if (rc) return rc;
+  uint8_t hdr[128];
+  shk_header(c, hdr);
+  FILE *f = fopen(path, "wb+");
+  if (!f) return SHK_ERR_IO;
+  size_t ok = fwrite(hdr, 128, 1, f);
+  ok += fwrite(buf.data(), buf.size(), 1, f);
+  fclose(f);
+  return ok == 2 ? SHK_OK : SHK_ERR_IO;
+}
+
+extern "C" int shk_import_blocks(shk_ctx *c, const void *src, uint64_t nbytes, uint64_t nelts, uint64_t ndistinct) {
+  if (!c || !src || nbytes != c->table_bytes) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(c->tab[c->cur], src, nbytes, hipMemcpyHostToDevice, c->stream));
+  { ProfScope ps(c, KP_MISC);
+    hipLaunchKernelGGL(k_build_fin, dim3(c->nregions / 256 + 1), dim3(256), 0, c->stream, c->tab[c->cur], c->nslots,
+                       c->nregions, c->fin[c->cur]); }
+  HIPCHK(hipGetLastError());
+  c->nelts = nelts; c->ndistinct = ndistinct;
+  return finish(c, 0);
+}
+
+extern "C" int shk_import_cqf(shk_ctx *c, const char *path) {
+  if (!c || !path) return SHK_ERR_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) return SHK_ERR_IO;
+  uint8_t hdr[128];
+  if (fread(hdr, 128, 1, f) != 1) { fclose(f); return SHK_ERR_IO; }
+  uint64_t size, nslots, key_bits, bps, nelts, nd;
+  memcpy(&size, hdr + 0, 8); memcpy(&nslots, hdr + 16, 8); memcpy(&key_bits, hdr + 32, 8); memcpy(&bps, hdr + 56, 8);
+  memcpy(&nelts, hdr + 88, 8); memcpy(&nd, hdr + 96, 8);
+  if (bps != 8 || nslots != c->nslots || key_bits != c->cfg.hb || size != c->table_bytes || c->q_lo != 0) { fclose(f); return SHK_ERR_ARG; }
+  std::vector<uint8_t> buf(size);
+  if (fread(buf.data(), size, 1, f) != 1) { fclose(f); return SHK_ERR_IO; }
+  fclose(f);
+  return shk_import_blocks(c, buf.data(), size, nelts, nd);
+}
+
+extern "C" int shk_lookup(shk_ctx *c, const uint64_t *keys, uint64_t n, int on_device, int mode, uint64_t *counts,
+                          uint8_t *was_traveled) {
+  if (!c || (n && (!keys || !counts)) || mode < 0 || mode > 2) return SHK_ERR_ARG;
+  if (n == 0) return SHK_OK;
+  HIPCHK(hipSetDevice(c->dev));
+  uint64_t *dk = nullptr, *dc = nullptr; uint8_t *dt = nullptr;
+  if (on_device) { dk = (uint64_t *)keys; dc = counts; dt = was_traveled; }
+  else {
+    HIPCHK(hipMalloc((void **)&dk, n * 8)); HIPCHK(hipMalloc((void **)&dc, n * 8)); HIPCHK(hipMalloc((void **)&dt, n));
+    HIPCHK(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  { ProfScope ps(c, KP_LOOKUP);
+    hipLaunchKernelGGL(k_lookup, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], dk, n, c->q_lo,
+                       c->nslots, mode, dc, dt); }
+  HIPCHK(hipGetLastError());
+  if (!on_device) {
+    HIPCHK(hipMemcpyAsync(counts, dc, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (was_traveled) HIPCHK(hipMemcpyAsync(was_traveled, dt, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(dk); hipFree(dc); hipFree(dt);
+  }
+  return finish(c, 0);
+}
+
+extern "C" int shk_profile_enable(shk_ctx *c, int on) { if (!c) return SHK_ERR_ARG; c->prof_on = on; return SHK_OK; }
+extern "C" int shk_profile_reset(shk_ctx *c) {
+  if (!c) return SHK_ERR_ARG;
+  for (int i = 0; i < KP_N; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return SHK_OK;
+}
+extern "C" int shk_profile_get(shk_ctx *c, shk_kernel_time *out, int cap) {
+  if (!c || !out) return SHK_ERR_ARG;
+  int n = 0;
+  for (int i = 0; i < KP_N && n < cap; i++) {
+    out[n].name = kp_names[i]; out[n].launches = c->prof_n[i]; out[n].ms = c->prof_ms[i]; n++;
+  }
+  return n;
+}

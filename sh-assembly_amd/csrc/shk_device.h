@@ -1,0 +1,207 @@
+// Device-side helpers shared by the kernels: wave/workgroup scans, unaligned
+// access to the packed 89-byte qfblock image, the counter codec.
+// gfx950 only: wavefront = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SHK_WAVE 64
+#define SHK_MAX_WAVES 16      // workgroups are at most 1024 threads
+#define SHK_BLOCK_BYTES 89    // reference qfblock at bits_per_slot = 8: cqf/gqf.c:63-86
+#define SHK_OFF_OCC 1         // occupieds word
+#define SHK_OFF_RUN 9         // runends word
+#define SHK_OFF_TRAV 17       // traveled word
+#define SHK_OFF_SLOTS 25      // 64 one-byte slots
+
+// One region = the quotients one workgroup owns in the merge kernels.
+#define SHK_REGION_LOG2 11
+#define SHK_REGION (1u << SHK_REGION_LOG2)             // 2048 quotients = 32 blocks
+#define SHK_REGION_BLOCKS (SHK_REGION / 64)
+#define SHK_IMG_BLOCKS 64                              // LDS image: own 32 blocks + 32 spill blocks
+#define SHK_IMG_SLOTS (SHK_IMG_BLOCKS * 64)            // 4096 slots
+#define SHK_IMG_BYTES (SHK_IMG_BLOCKS * SHK_BLOCK_BYTES)
+#define SHK_HCAP 4096                                  // LDS hash capacity (distinct new keys per region)
+#define SHK_CHUNK_BITS 12                              // chunk index field of a key word
+#define SHK_MAX_CHUNKS (1u << SHK_CHUNK_BITS)
+#define SHK_HIST_BINS 32
+
+// error bits raised by kernels (ctx->d_err), reported through the C ABI
+#define SHK_E_OLD_EXTENT   (1u << 0)   // a region's old runs spill further than the LDS image
+#define SHK_E_NEW_EXTENT   (1u << 1)   // a region's new runs spill further than the LDS image
+#define SHK_E_HASH_FULL    (1u << 2)   // more distinct new keys in one region than SHK_HCAP
+#define SHK_E_TABLE_FULL   (1u << 3)   // runs would pass xnslots
+#define SHK_E_CORRUPT      (1u << 4)   // occupieds/runends disagree
+#define SHK_E_BAD_FASTQ    (1u << 5)   // read longer than 65535 / k out of range
+#define SHK_E_KEYS_FULL    (1u << 6)   // batch produced more keys than the key buffer holds
+#define SHK_E_RUN_TOO_LONG (1u << 7)
+
+__device__ __forceinline__ unsigned shk_lane() { return threadIdx.x & (SHK_WAVE - 1); }
+__device__ __forceinline__ unsigned shk_wave() { return threadIdx.x / SHK_WAVE; }
+
+__device__ __forceinline__ uint64_t shk_rol64(uint64_t v, unsigned s) {
+  s &= 63;
+  return s ? (v << s) | (v >> (64 - s)) : v;
+}
+__device__ __forceinline__ uint64_t shk_ror64(uint64_t v, unsigned s) {
+  s &= 63;
+  return s ? (v >> s) | (v << (64 - s)) : v;
+}
+
+// ---- wave scans (64 lanes, shuffle based)
+__device__ __forceinline__ uint32_t shk_wave_incl_add(uint32_t x) {
+  unsigned lane = shk_lane();
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    uint32_t y = __shfl_up(x, d);
+    if (lane >= (unsigned)d) x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ uint64_t shk_wave_incl_add64(uint64_t x) {
+  unsigned lane = shk_lane();
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    uint64_t y = __shfl_up(x, d);
+    if (lane >= (unsigned)d) x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ uint64_t shk_wave_incl_xor64(uint64_t x) {
+  unsigned lane = shk_lane();
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    uint64_t y = __shfl_up(x, d);
+    if (lane >= (unsigned)d) x ^= y;
+  }
+  return x;
+}
+
+// ---- workgroup exclusive scan of one u32 per thread. `scratch` is SHK_MAX_WAVES+1 words of LDS.
+// Returns the exclusive prefix; *total gets the workgroup sum. Ends with a barrier.
+__device__ __forceinline__ uint32_t shk_block_exscan(uint32_t v, uint32_t *total, uint32_t *scratch) {
+  unsigned lane = shk_lane(), wave = shk_wave(), nw = blockDim.x / SHK_WAVE;
+  uint32_t incl = shk_wave_incl_add(v);
+  if (lane == SHK_WAVE - 1) scratch[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < nw ? scratch[lane] : 0;
+    uint32_t wi = shk_wave_incl_add(w);
+    if (lane < nw) scratch[lane] = wi - w;
+    if (lane == nw - 1) scratch[SHK_MAX_WAVES] = wi;
+  }
+  __syncthreads();
+  uint32_t res = scratch[wave] + incl - v;
+  *total = scratch[SHK_MAX_WAVES];
+  __syncthreads();
+  return res;
+}
+__device__ __forceinline__ uint64_t shk_block_exscan64(uint64_t v, uint64_t *total, uint64_t *scratch) {
+  unsigned lane = shk_lane(), wave = shk_wave(), nw = blockDim.x / SHK_WAVE;
+  uint64_t incl = shk_wave_incl_add64(v);
+  if (lane == SHK_WAVE - 1) scratch[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint64_t w = lane < nw ? scratch[lane] : 0;
+    uint64_t wi = shk_wave_incl_add64(w);
+    if (lane < nw) scratch[lane] = wi - w;
+    if (lane == nw - 1) scratch[SHK_MAX_WAVES] = wi;
+  }
+  __syncthreads();
+  uint64_t res = scratch[wave] + incl - v;
+  *total = scratch[SHK_MAX_WAVES];
+  __syncthreads();
+  return res;
+}
+// workgroup sum of one u64 per thread (result valid in every thread). Ends with a barrier.
+__device__ __forceinline__ uint64_t shk_block_sum64(uint64_t v, uint64_t *scratch) {
+  uint64_t t;
+  shk_block_exscan64(v, &t, scratch);
+  return t;
+}
+
+// ---- "free pointer" functions f -> max(f + a, b): how a sequence of runs moves the
+// first free slot (a = total run length, b = where it ends when nothing spills in).
+// Composition is associative; identity is (0, -inf).
+#define SHK_NEG_INF (-(1LL << 60))
+struct ShkMP {
+  long long a, b;
+};
+__device__ __forceinline__ ShkMP shk_mp_compose(ShkMP first, ShkMP second) {
+  ShkMP r;
+  r.a = first.a + second.a;
+  long long t = first.b + second.a;
+  r.b = t > second.b ? t : second.b;
+  if (r.b < SHK_NEG_INF) r.b = SHK_NEG_INF;
+  return r;
+}
+__device__ __forceinline__ long long shk_mp_apply(ShkMP m, long long f) {
+  long long t = f + m.a;
+  return t > m.b ? t : m.b;
+}
+
+// ---- bytes of the packed block image (global or LDS): unaligned little-endian access
+__device__ __forceinline__ uint64_t shk_ld64(const uint8_t *p) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i);
+  return v;
+}
+__device__ __forceinline__ void shk_st64(uint8_t *p, uint64_t v) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+// position of the n-th (0-based) set bit of w; 64 when there are not that many
+__device__ __forceinline__ unsigned shk_select64(uint64_t w, unsigned n) {
+  if ((unsigned)__popcll(w) <= n) return 64;
+  unsigned pos = 0;
+#pragma unroll
+  for (int width = 32; width >= 1; width >>= 1) {
+    uint64_t low = w & ((1ULL << width) - 1);
+    unsigned c = (unsigned)__popcll(low);
+    if (n >= c) { n -= c; w >>= width; pos += width; } else { w = low; }
+  }
+  return pos;
+}
+
+// ---- counter codec, cqf/gqf.c:1225-1255 (encode_counter) at bits_per_slot = 8:
+// count 1 -> [r]; count c+1 >= 2 -> [r, (0 if top digit > r), d_m|0x80 .. d_1|0x80, d_0],
+// base-128 digits of c.
+__device__ __forceinline__ unsigned shk_enc_len(unsigned rem, uint64_t count) {
+  if (count <= 1) return (unsigned)count;
+  uint64_t c = count - 1;
+  unsigned nd = 1;
+  uint64_t t = c >> 7;
+  while (t) { nd++; t >>= 7; }
+  unsigned top = (unsigned)((c >> (7 * (nd - 1))) & 0x7f);
+  if (nd > 1) top |= 0x80;
+  return 1 + nd + (top > rem ? 1 : 0);
+}
+// writes the encoding to dst[0..len) and returns len
+__device__ __forceinline__ unsigned shk_enc_write(uint8_t *dst, unsigned rem, uint64_t count) {
+  dst[0] = (uint8_t)rem;
+  if (count <= 1) return 1;
+  uint64_t c = count - 1;
+  unsigned nd = 1;
+  uint64_t t = c >> 7;
+  while (t) { nd++; t >>= 7; }
+  unsigned top = (unsigned)((c >> (7 * (nd - 1))) & 0x7f);
+  if (nd > 1) top |= 0x80;
+  unsigned n = 1;
+  if (top > rem) dst[n++] = 0;
+  for (int i = (int)nd - 1; i >= 1; i--) dst[n++] = (uint8_t)(((c >> (7 * i)) & 0x7f) | 0x80);
+  dst[n++] = (uint8_t)(c & 0x7f);
+  return n;
+}
+// decode_counter, cqf/gqf.c:1259-1299, over a byte image of slots. `is_last` = the
+// entry's first slot carries the runend bit. Returns the number of slots the entry takes.
+__device__ __forceinline__ unsigned shk_dec(const uint8_t *s, bool first_is_runend, uint64_t *count) {
+  unsigned rem = s[0];
+  if (first_is_runend) { *count = 1; return 1; }
+  unsigned digit = s[1];
+  if (digit > rem) { *count = 1; return 1; }
+  unsigned n = 1;
+  uint64_t cnt = 0;
+  if (digit == 0) { n++; digit = s[n]; }
+  while (digit & 0x80) { cnt = cnt * 128 + (digit & 0x7f); n++; digit = s[n]; }
+  cnt = cnt * 128 + digit;
+  *count = cnt + 1;
+  return n + 1;
+}

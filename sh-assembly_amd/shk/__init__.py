@@ -1,0 +1,217 @@
+"""ctypes binding of libshk.so (include/shk.h) for tests, bench.py and smoke().
+
+This is plumbing, not the product: the product is the C ABI and the C++ host tools in
+sh-assembly_amd/host. The binding opens the in-tree libshk.so built by hipcc and fails
+loudly when it is missing -- there is no CPU fallback. (The CPU test-suite passes the
+path of the emulator build explicitly; see tests/emu.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libshk.so")
+
+MAX_CHUNKS = 4096
+
+
+class Config(C.Structure):
+    _fields_ = [("qb", C.c_uint32), ("hb", C.c_uint32), ("seed", C.c_uint32), ("k", C.c_uint32),
+                ("ndistinct_for_denoise", C.c_uint64), ("num_denoise", C.c_uint32), ("reserved0", C.c_uint32),
+                ("min_denoise_len", C.c_uint64), ("max_batch_bytes", C.c_uint64), ("max_batch_keys", C.c_uint64),
+                ("max_batch_reads", C.c_uint64), ("device", C.c_int32), ("shard_index", C.c_uint32),
+                ("num_shards", C.c_uint32), ("threads_per_group", C.c_uint32), ("hash_groups", C.c_uint32),
+                ("max_level_bits", C.c_uint32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("kmers", C.c_uint64), ("new_distinct", C.c_uint64), ("removed", C.c_uint64),
+                ("denoise_rounds", C.c_uint32), ("chunks", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Totals(C.Structure):
+    _fields_ = [("nelts", C.c_uint64), ("ndistinct", C.c_uint64), ("rounds_left", C.c_uint32),
+                ("rounds_done", C.c_uint32), ("nslots", C.c_uint64), ("xnslots", C.c_uint64),
+                ("nblocks", C.c_uint64), ("table_bytes", C.c_uint64), ("free_pointer", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("ms", C.c_double)]
+
+
+class ShkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libshk error {code}: {msg}")
+        self.code = code
+
+
+EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_denoise",
+           "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
+           "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
+           "shk_last_error_bits"]
+
+_libs = {}
+
+
+def load(path=None):
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `make -C sh-assembly_amd` (hipcc, gfx950). "
+                          "There is no CPU fallback.")
+    L = C.CDLL(path)
+    u64, u32, i32, vp = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p
+    pu64 = C.POINTER(u64)
+    L.shk_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.shk_destroy.argtypes = [vp]
+    L.shk_destroy.restype = None
+    L.shk_count_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(BatchStats)]
+    L.shk_hash_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(vp), pu64]
+    L.shk_count_words.argtypes = [vp, vp, u64, u32, C.POINTER(BatchStats)]
+    L.shk_denoise.argtypes = [vp, pu64]
+    L.shk_stats.argtypes = [vp, C.POINTER(Totals)]
+    L.shk_header.argtypes = [vp, C.c_char_p]
+    L.shk_export_blocks.argtypes = [vp, vp, u64]
+    L.shk_export_cqf.argtypes = [vp, C.c_char_p]
+    L.shk_import_cqf.argtypes = [vp, C.c_char_p]
+    L.shk_import_blocks.argtypes = [vp, vp, u64, u64, u64]
+    L.shk_lookup.argtypes = [vp, vp, u64, i32, i32, vp, vp]
+    L.shk_profile_enable.argtypes = [vp, i32]
+    L.shk_profile_get.argtypes = [vp, C.POINTER(KernelTime), i32]
+    L.shk_profile_reset.argtypes = [vp]
+    L.shk_strerror.argtypes = [i32]
+    L.shk_strerror.restype = C.c_char_p
+    L.shk_last_error_bits.argtypes = [vp]
+    L.shk_last_error_bits.restype = u32
+    _libs[path] = L
+    return L
+
+
+def fixed_chunks(total_bytes, part_size):
+    """helper: chunk table for a buffer cut every `part_size` bytes (caller guarantees record boundaries)"""
+    offs = list(range(0, total_bytes, part_size))
+    lens = [min(part_size, total_bytes - o) for o in offs]
+    return offs, lens
+
+
+class Context:
+    """One filter (or one shard of it) on one GPU."""
+
+    def __init__(self, qb, k, trigger=(1 << 62), num_denoise=0, min_denoise_len=0, max_batch_bytes=1 << 26,
+                 max_batch_keys=1 << 26, max_batch_reads=0, device=0, shard_index=0, num_shards=1, seed=2038074761,
+                 threads_per_group=0, hash_groups=0, max_level_bits=0, lib_path=None):
+        self.L = load(lib_path)
+        self.cfg = Config(qb=qb, hb=qb + 8, seed=seed, k=k, ndistinct_for_denoise=trigger, num_denoise=num_denoise,
+                          min_denoise_len=min_denoise_len, max_batch_bytes=max_batch_bytes,
+                          max_batch_keys=max_batch_keys, max_batch_reads=max_batch_reads, device=device,
+                          shard_index=shard_index, num_shards=num_shards, threads_per_group=threads_per_group,
+                          hash_groups=hash_groups, max_level_bits=max_level_bits)
+        h = C.c_void_p()
+        self._chk(self.L.shk_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ShkError(rc, self.L.shk_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.shk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _tab(vals):
+        return (C.c_uint64 * len(vals))(*vals)
+
+    def count_chunks(self, text, chunk_off, chunk_len, on_device=False, text_bytes=None):
+        """text: bytes (host) or an integer device pointer (on_device=True, text_bytes given)"""
+        st = BatchStats()
+        if on_device:
+            ptr, n = C.c_void_p(int(text)), int(text_bytes)
+        else:
+            buf = (C.c_char * len(text)).from_buffer_copy(text) if not isinstance(text, C.Array) else text
+            ptr, n = C.cast(buf, C.c_void_p), len(text)
+        self._chk(self.L.shk_count_chunks(self.h, ptr, 1 if on_device else 0, n, self._tab(chunk_off),
+                                          self._tab(chunk_len), len(chunk_off), C.byref(st)))
+        return st.as_dict()
+
+    def hash_chunks(self, text, chunk_off, chunk_len, on_device=False, text_bytes=None):
+        """returns (device pointer, nwords)"""
+        dp, nw = C.c_void_p(), C.c_uint64()
+        if on_device:
+            ptr, n = C.c_void_p(int(text)), int(text_bytes)
+        else:
+            buf = (C.c_char * len(text)).from_buffer_copy(text)
+            ptr, n = C.cast(buf, C.c_void_p), len(text)
+        self._chk(self.L.shk_hash_chunks(self.h, ptr, 1 if on_device else 0, n, self._tab(chunk_off),
+                                         self._tab(chunk_len), len(chunk_off), C.byref(dp), C.byref(nw)))
+        return dp.value, nw.value
+
+    def count_words(self, d_words, nwords, nchunks=1):
+        st = BatchStats()
+        self._chk(self.L.shk_count_words(self.h, C.c_void_p(int(d_words) if d_words else 0), nwords, nchunks,
+                                         C.byref(st)))
+        return st.as_dict()
+
+    def denoise(self):
+        r = C.c_uint64()
+        self._chk(self.L.shk_denoise(self.h, C.byref(r)))
+        return r.value
+
+    def totals(self):
+        t = Totals()
+        self._chk(self.L.shk_stats(self.h, C.byref(t)))
+        return t
+
+    def header(self):
+        b = C.create_string_buffer(128)
+        self._chk(self.L.shk_header(self.h, b))
+        return b.raw
+
+    def blocks(self):
+        n = self.totals().table_bytes
+        b = C.create_string_buffer(n)
+        self._chk(self.L.shk_export_blocks(self.h, C.cast(b, C.c_void_p), n))
+        return b.raw
+
+    def export_cqf(self, path):
+        self._chk(self.L.shk_export_cqf(self.h, path.encode()))
+
+    def import_cqf(self, path):
+        self._chk(self.L.shk_import_cqf(self.h, path.encode()))
+
+    def import_blocks(self, data, nelts=0, ndistinct=0):
+        b = (C.c_char * len(data)).from_buffer_copy(data)
+        self._chk(self.L.shk_import_blocks(self.h, C.cast(b, C.c_void_p), len(data), nelts, ndistinct))
+
+    def lookup(self, keys, mode=2):
+        n = len(keys)
+        k = (C.c_uint64 * max(n, 1))(*keys)
+        c = (C.c_uint64 * max(n, 1))()
+        t = (C.c_uint8 * max(n, 1))()
+        self._chk(self.L.shk_lookup(self.h, C.cast(k, C.c_void_p), n, 0, mode, C.cast(c, C.c_void_p),
+                                    C.cast(t, C.c_void_p)))
+        return [c[i] for i in range(n)], [t[i] for i in range(n)]
+
+    def profile(self, on=True):
+        self._chk(self.L.shk_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.shk_profile_reset(self.h))
+
+    def profile_get(self):
+        arr = (KernelTime * 32)()
+        n = self.L.shk_profile_get(self.h, arr, 32)
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].ms) for i in range(n) if arr[i].launches}
+
+    def last_error_bits(self):
+        return self.L.shk_last_error_bits(self.h)
