@@ -405,24 +405,38 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
 // rounds where the t = 1 reference would: after the first chunk at which
 // ndistinct >= trigger while rounds are left (CQF_mt.h:837, 860-869).
 static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_batch_stats *st) {
+  // A summary over chunks that will turn out to lie behind a deNoise point is speculative:
+  // "table full"/"extent" raised by its free-pointer scan mean nothing then.
+  const uint32_t soft = SHK_E_TABLE_FULL | SHK_E_NEW_EXTENT;
   uint32_t lo = 0;
   while (lo < nchunks) {
     uint32_t hi = nchunks - 1;
     const bool watch = c->rounds_left > 0;
-    uint32_t span = hi - lo + 1, shift = 0;
-    while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
     MergeOut o;
-    int rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o);
-    if (rc) return rc;
-    if (o.err) return map_err_bits(o.err);
+    uint32_t shift;
+    int rc;
+    for (;;) {
+      uint32_t span = hi - lo + 1;
+      shift = 0;
+      while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
+      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o);
+      if (rc) return rc;
+      if (o.err & ~(soft | SHK_E_HASH_FULL)) return map_err_bits(o.err & ~(soft | SHK_E_HASH_FULL));
+      if (o.err & SHK_E_HASH_FULL) {
+        // more distinct new keys in one region than its LDS hash holds: take fewer chunks at once
+        if (hi == lo) return SHK_ERR_REGION;
+        hi = lo + (hi - lo) / 2;
+        continue;
+      }
+      break;
+    }
     bool fire = false;
     if (watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise) {
       // locate the first chunk at which the running distinct count reaches the trigger
       uint32_t base = lo;
-      uint64_t acc = c->ndistinct;  // distinct keys before chunk `base`
       for (;;) {
         uint32_t bin = 0;
-        uint64_t run = acc + o.before;
+        uint64_t run = c->ndistinct + o.before;
         for (bin = 0; bin < SHK_HIST_BINS; bin++) {
           if (run + o.hist[bin] >= c->cfg.ndistinct_for_denoise) break;
           run += o.hist[bin];
@@ -439,14 +453,14 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
         base = b_lo;
         rc = merge_summary(c, words, lo, b_hi, base, shift, 0, &o);
         if (rc) return rc;
-        if (o.err) return map_err_bits(o.err);
+        if (o.err & ~soft) return map_err_bits(o.err & ~soft);
       }
       fire = true;
       // summary for exactly the chunks [lo, hi]
       rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o);
       if (rc) return rc;
-      if (o.err) return map_err_bits(o.err);
     }
+    if (o.err) return map_err_bits(o.err);
     rc = merge_write(c, words, lo, hi, 0);
     if (rc) return rc;
     c->ndistinct += o.newd;
@@ -487,10 +501,13 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0);
   if (rc) return finish(c, rc);
   uint32_t bits = 0;
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
   if (fetch_err(c, &bits)) return SHK_ERR_HIP;
   if (bits) { prof_collect(c); return map_err_bits(bits); }
+  const uint64_t nwords = c->h_pinned[42];
+  if (nwords > c->cfg.max_batch_keys) { prof_collect(c); return SHK_ERR_BATCH; }
   int dst = 0;
-  rc = partition_stage(c, 0, c->cfg.max_batch_keys, &dst);
+  rc = partition_stage(c, 0, nwords, &dst);
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, &st);
   if (stats) *stats = st;

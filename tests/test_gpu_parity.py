@@ -16,8 +16,8 @@ def _ctx(**kw):
     return shk.Context(**kw)
 
 
-@pytest.mark.parametrize("qb,k,nreads,G,L", [(13, 28, 150, 1500, 100), (16, 47, 1500, 20000, 150),
-                                             (18, 31, 6000, 60000, 150), (20, 47, 20000, 300000, 150)])
+@pytest.mark.parametrize("qb,k,nreads,G,L", [(13, 28, 150, 1500, 100), (17, 47, 1500, 20000, 150),
+                                             (19, 31, 6000, 60000, 150), (21, 47, 20000, 300000, 150)])
 def test_count_matches_oracle(qb, k, nreads, G, L):
     g = synth.make_genome(G, 1)
     fq = synth.make_fastq(g, nreads, L, 0.01, seed=3, n_frac=0.05, short_frac=0.02, lower_frac=0.02)
