@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--reads-per-step", type=int, default=2_000_000)
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--qb", type=int, default=0, help="override the filter size (default: README sizing)")
+    ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostics: SHK_ABLATE bits applied to the timed steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/all-to-all code path even with one rank")
     args = ap.parse_args()
@@ -223,7 +225,7 @@ def main():
 
     ctx = shk.Context(qb=qb, k=K, trigger=(trigger if not sharded else (1 << 62)), num_denoise=(nd if not sharded else 0),
                       max_batch_bytes=64, max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
-                      max_batch_reads=R + 1024, device=local_rank, shard_index=rank, num_shards=world)
+                      max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
     tot = ctx.totals()
 
     genome = torch.randint(0, 4, (args.genome,), device=device, dtype=torch.uint8,
@@ -278,6 +280,8 @@ def main():
     counted = 0
     removed_total = 0
     rounds_fired = 0
+    if args.ablate:
+        os.environ["SHK_ABLATE"] = str(args.ablate)
     ctx.profile(True)
     ctx.profile_reset()
     if dist:

@@ -61,7 +61,7 @@ typedef struct shk_config {
   int32_t device;                  /* HIP device ordinal */
   uint32_t shard_index;            /* this context owns quotients [shard_index, shard_index+1) * 2^qb / num_shards */
   uint32_t num_shards;             /* 0 or 1 = whole filter; otherwise a power of two */
-  uint32_t threads_per_group;      /* 0 = 256; tests may lower it */
+  uint32_t threads_per_group;      /* 0 = 512; tests may lower it */
   uint32_t hash_groups;            /* 0 = auto; grid of the grid-stride kernels */
   uint32_t max_level_bits;         /* 0 = 10; digit bits per partition level (tests lower it) */
 } shk_config;

@@ -30,11 +30,13 @@ struct ShkMergeArgs {
   uint32_t hb;
   uint32_t chunk_lo, chunk_hi;    // only words whose chunk index lies in [lo, hi] take part
   uint32_t hist_base, hist_shift; // coarse histogram of the first chunk of every NEW key
+  int want_hist;                  // 0: totals only (the common case: no deNoise point inside the batch)
   int denoise;                    // 1: drop entries whose count is exactly 1 (no new keys)
   uint32_t *summary;              // [2*nregions]: T, c (relative to the region start; 0 = empty)
   unsigned long long *counters;   // 0 new distinct, 1 occurrences added, 2 removed, 3 new before hist_base
   unsigned long long *hist;       // [SHK_HIST_BINS]
   uint32_t *err;
+  uint32_t ablate;                // diagnostics only (SHK_ABLATE): skip phases to time them; results invalid
 };
 
 __device__ __forceinline__ unsigned shk_img_slot_off(unsigned p) {
@@ -158,7 +160,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
 
   // ---- fold this region's new keys into the LDS hash
   uint64_t my_added = 0;
-  if (A.words) {
+  if (A.words && !(A.ablate & 1)) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
     const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
     for (uint64_t i = kb + tid; i < ke; i += nthr) {
@@ -230,6 +232,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   }
 
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
+  if (!(A.ablate & 16))
   for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
     if (hkey[h] != SHK_EMPTY) atomicAdd(&qcnt[hkey[h] >> (SHK_CHUNK_BITS + 8)], 1u);
   __syncthreads();
@@ -244,6 +247,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     if (tid == nthr - 1) qoff[SHK_REGION] = (uint16_t)ex;
   }
   __syncthreads();
+  if (!(A.ablate & 16))
   for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
     if (hkey[h] != SHK_EMPTY) {
       uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
@@ -270,7 +274,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
     uint32_t len = 0;
-    if (q < nq) {
+    if (q < nq && !(A.ablate & 2)) {
       const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
       uint32_t opos = 0, oend = 0;
       bool ohas = false;
@@ -305,10 +309,11 @@ __global__ void k_region_merge(ShkMergeArgs A) {
         if (A.denoise && total < 2 && !prot) { my_removed++; continue; }
         if (!WRITE && is_new) {
           my_new++;
-          if (mc < A.hist_base) my_before++;
+          if (!A.want_hist) {
+          } else if (mc < A.hist_base) my_before++;
           else {
             uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
-            atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
+            if (!(A.ablate & 32)) atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
           }
         }
         len += shk_enc_len(rem, total);
@@ -376,7 +381,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   uint32_t *nimg32 = reinterpret_cast<uint32_t *>(nimg);
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
-    if (q >= nq || qcnt[q] == 0) continue;
+    if (q >= nq || qcnt[q] == 0 || (A.ablate & 4)) continue;
     const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
     uint32_t opos = 0, oend = 0;
     bool ohas = false;
@@ -438,6 +443,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   // [out_lo, out_hi) only; the first and last runends byte may be shared with the
   // neighbouring regions' runs, so they are OR-ed in atomically (B was zeroed).
   uint8_t *tb = A.tabB + b0 * SHK_BLOCK_BYTES;
+  if (A.ablate & 8) return;
   for (uint32_t i = tid; i < nown * 9; i += nthr) {
     const uint32_t blk = i / 9, byte = i % 9;
     tb[blk * SHK_BLOCK_BYTES + byte] = nimg[blk * SHK_BLOCK_BYTES + byte];

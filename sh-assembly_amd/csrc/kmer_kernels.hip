@@ -19,6 +19,7 @@
 #define SHK_SEED_C 0x3193c18562a02b4cULL
 #define SHK_SEED_G 0x20323ed082572324ULL
 #define SHK_SEED_T 0x295549f54be24456ULL
+#define SHK_HASH_WAVES 4                   // waves per workgroup of k_hash_reads
 #define SHK_MAX_K 191                     // ring of 256 prefix values per wave
 #define SHK_MAX_READ 65535                // a record fits the chunker's overhead (CQF_mt.h:764)
 
@@ -193,8 +194,8 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
                              const uint64_t *nreads_p, const uint64_t *reads_base, uint32_t nchunks,
                              uint32_t chunk_first, const uint64_t *key_base, uint32_t k, uint32_t hb,
                              uint64_t *words, uint64_t cap, uint32_t *err) {
-  __shared__ uint64_t ringG[SHK_MAX_WAVES][256];
-  __shared__ uint64_t ringH[SHK_MAX_WAVES][256];
+  __shared__ uint64_t ringG[SHK_HASH_WAVES][256];  // launched with at most SHK_HASH_WAVES waves per group
+  __shared__ uint64_t ringH[SHK_HASH_WAVES][256];
   const uint64_t nreads = *nreads_p;
   const unsigned lane = shk_lane(), wv = shk_wave();
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);

@@ -170,7 +170,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
       nb <<= bits;
     }
   }
-  c->threads = cfg->threads_per_group ? cfg->threads_per_group : 256;
+  c->threads = cfg->threads_per_group ? cfg->threads_per_group : 512;
   if (c->threads < 64 || c->threads > 1024 || (c->threads & (c->threads - 1))) { delete c; return SHK_ERR_ARG; }
   c->hash_groups = cfg->hash_groups ? cfg->hash_groups : 2048;
   c->rounds_left = cfg->num_denoise;
@@ -296,7 +296,8 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   // total = key_base[nreads] -> d_scalars[1]
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->d_key_base + nreads, 8, hipMemcpyDeviceToDevice, c->stream));
   { ProfScope ps(c, KP_HASH);
-    hipLaunchKernelGGL(k_hash_reads, dim3(groups), dim3(c->threads), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
+    const uint32_t ht = c->threads < SHK_HASH_WAVES * SHK_WAVE ? c->threads : SHK_HASH_WAVES * SHK_WAVE;
+    hipLaunchKernelGGL(k_hash_reads, dim3(groups * (c->threads / ht)), dim3(ht), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
                        c->d_scalars + 0, c->d_reads_base, nchunks, chunk_first, c->d_key_base, c->cfg.k, c->cfg.hb,
                        c->d_words[0], c->cfg.max_batch_keys, c->d_err); }
   HIPCHK(hipGetLastError());
@@ -340,20 +341,22 @@ struct MergeOut {
 };
 
 static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase,
-                      uint32_t hshift, int denoise) {
+                      uint32_t hshift, int denoise, int want_hist = 0) {
+  A->want_hist = want_hist;
   A->tabA = c->tab[c->cur]; A->tabB = c->tab[c->cur ^ 1];
   A->finA = c->fin[c->cur]; A->finB = c->fin[c->cur ^ 1];
   A->words = words; A->region_base = c->d_base[c->nlevels];
   A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
+  { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
 // summary launch + free-pointer scan, then read the statistics back (one synchronisation)
 static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase, uint32_t hshift,
-                         int denoise, MergeOut *o) {
+                         int denoise, MergeOut *o, int want_hist = 0) {
   ShkMergeArgs A;
-  fill_args(c, &A, words, lo, hi, hbase, hshift, denoise);
+  fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SUM);
     hipLaunchKernelGGL((k_region_merge<false>), dim3(c->nregions), dim3(c->threads), 0, c->stream, A); }
@@ -432,8 +435,12 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
     }
     bool fire = false;
     if (watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise) {
-      // locate the first chunk at which the running distinct count reaches the trigger
+      // locate the first chunk at which the running distinct count reaches the trigger:
+      // only now is the per-chunk histogram of first occurrences needed
       uint32_t base = lo;
+      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, 1);
+      if (rc) return rc;
+      if (o.err & ~soft) return map_err_bits(o.err & ~soft);
       for (;;) {
         uint32_t bin = 0;
         uint64_t run = c->ndistinct + o.before;
@@ -451,7 +458,7 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
         shift = 0;
         while ((span2 + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
         base = b_lo;
-        rc = merge_summary(c, words, lo, b_hi, base, shift, 0, &o);
+        rc = merge_summary(c, words, lo, b_hi, base, shift, 0, &o, 1);
         if (rc) return rc;
         if (o.err & ~soft) return map_err_bits(o.err & ~soft);
       }

@@ -1,0 +1,110 @@
+"""CPU tests of the kernel LOGIC: the unmodified sources of sh-assembly_amd/csrc compiled
+with g++ against tests/emu/hip/hip_runtime.h (workgroups as OS threads, waves of 64 with
+barrier-backed shuffles) and driven through the same C ABI. These run without a GPU; the
+real parity tests are tests/test_gpu_parity.py (-m gpu) on libshk.so built by hipcc.
+Sizes are tiny because every thread of a workgroup is an OS thread here."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+import cqflibs
+import synth
+from fastq_util import chunks_by_records, oracle_header, oracle_t1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libshk_emu.so")
+
+
+@pytest.fixture(scope="module")
+def shk():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    import shk as m
+    return m
+
+
+def _ctx(shk, **kw):
+    return shk.Context(threads_per_group=64, hash_groups=2, lib_path=EMU, **kw)
+
+
+def test_key_stream_is_reference_order(shk):
+    """k_hash_reads emits exactly the keys reads_to_kmers would insert, in its order,
+    including the 'N' restart rule, short reads and lower case"""
+    O = cqflibs.oracle()
+    fq = synth.make_fastq(synth.make_genome(3000, 1), 100, 100, 0.01, seed=3, n_frac=0.25, short_frac=0.1,
+                          lower_frac=0.05)
+    offs, lens = chunks_by_records(fq, 45)
+    for k, qb in ((28, 12), (47, 12), (64, 14), (100, 12)):
+        ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=1 << 20, max_batch_keys=1 << 16)
+        dp, nw = ctx.hash_chunks(fq, offs, lens)
+        words = (C.c_uint64 * max(nw, 1)).from_address(dp)
+        hb = qb + 8
+        exp, chunk = [], []
+        for ci, (a, n) in enumerate(zip(offs, lens)):
+            ks = O.chunk_keys(fq[a:a + n], k, hb)
+            exp += ks
+            chunk += [ci] * len(ks)
+        assert nw == len(exp)
+        assert [w & ((1 << hb) - 1) for w in words[:nw]] == exp
+        assert [w >> hb for w in words[:nw]] == chunk
+        ctx.close()
+
+
+def test_count_and_denoise_schedule(shk):
+    """hash -> partition (3 levels forced) -> merge -> deNoise rounds where the t = 1 schedule
+    fires them; table bytes, header and counters equal the oracle's"""
+    fq = synth.make_fastq(synth.make_genome(1200, 7), 160, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
+    offs, lens = chunks_by_records(fq, 9)
+    qb, k, trig, nd, ml = 13, 28, 2300, 3, 64
+    ctx = _ctx(shk, qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=1 << 20,
+               max_batch_keys=1 << 16, max_level_bits=1)
+    half = len(offs) // 2
+    s1 = ctx.count_chunks(fq, offs[:half], lens[:half])
+    s2 = ctx.count_chunks(fq, offs[half:], lens[half:])
+    removed = s1["removed"] + s2["removed"] + ctx.denoise()
+    rounds = s1["denoise_rounds"] + s2["denoise_rounds"] + 1
+    q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, trig, nd, True, ml)
+    assert not q.full()
+    assert (rounds, removed) == (orounds, oremoved)
+    assert orounds >= 2
+    t = ctx.totals()
+    assert (t.nelts, t.ndistinct) == (q.nelts(), q.ndistinct())
+    assert ctx.blocks() == q.blocks()
+    assert ctx.header() == oracle_header(q)
+    # lookups + traveled marks against the oracle
+    keys = [kc[0] for kc in q.dump()[:40]] + [12345, 1 << 20, (1 << (qb + 8)) - 1]
+    cnt, _ = ctx.lookup(keys, mode=2)
+    assert cnt == [q.count(x) for x in keys]
+    _, t1 = ctx.lookup(keys, mode=1)
+    _, t2 = ctx.lookup(keys, mode=1)
+    exp1 = [q.count_set_traveled(x)[0] for x in keys]
+    exp2 = [q.count_set_traveled(x)[0] for x in keys]
+    assert (t1, t2) == (exp1, exp2)
+    assert ctx.blocks() == q.blocks()
+    ctx.close()
+    q.free()
+
+
+def test_import_then_count(shk, tmp_path):
+    """a .cqf written by the oracle is imported, more reads are counted on top"""
+    fq = synth.make_fastq(synth.make_genome(1000, 5), 80, 80, 0.01, seed=9)
+    offs, lens = chunks_by_records(fq, 20)
+    qb, k = 12, 31
+    q, _, _ = oracle_t1(fq, offs[:2], lens[:2], k, qb)
+    p = str(tmp_path / "a.cqf")
+    q.serialize(p)
+    ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=1 << 20, max_batch_keys=1 << 16)
+    ctx.import_cqf(p)
+    assert ctx.blocks() == q.blocks()
+    ctx.count_chunks(fq, offs[2:], lens[2:])
+    for a, n in zip(offs[2:], lens[2:]):
+        q.reads_to_kmers(fq[a:a + n], k)
+    assert ctx.blocks() == q.blocks()
+    p2 = str(tmp_path / "b.cqf")
+    p3 = str(tmp_path / "c.cqf")
+    ctx.export_cqf(p2)
+    q.serialize(p3)
+    assert open(p2, "rb").read() == open(p3, "rb").read()
+    ctx.close()
+    q.free()
