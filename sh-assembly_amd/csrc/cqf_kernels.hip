@@ -3,8 +3,9 @@
 // the deNoise sweep (qf_clean_singleton :2792-2876, driven by CQF_mt.h:884-901,999-1039).
 //
 // The table in HBM is the reference's own byte layout (89-byte packed qfblocks,
-// gqf.c:63-86), so export is a plain copy. One workgroup owns one region of 2048
-// quotients (32 blocks). It stages the region's old bytes in LDS, folds the batch's keys
+// gqf.c:63-86), so export is a plain copy. One WAVE owns one region of 256 quotients
+// (4 blocks; the kernels are launched with 64-thread workgroups, so every barrier is a
+// wave-local no-op). It stages the region's old bytes in LDS, folds the batch's keys
 // for that region into an LDS hash, merges old runs and new keys per quotient, and
 // re-encodes the runs at their canonical positions (run of q starts at max(q, end of
 // previous run + 1); remainders ascending; counters per encode_counter :1225-1255).
@@ -17,6 +18,7 @@
 #include "shk_device.h"
 
 #define SHK_EMPTY 0xFFFFFFFFu
+#define SHK_SUM_STRIDE 6
 
 struct ShkMergeArgs {
   const uint8_t *tabA;
@@ -32,7 +34,8 @@ struct ShkMergeArgs {
   uint32_t hist_base, hist_shift; // coarse histogram of the first chunk of every NEW key
   int want_hist;                  // 0: totals only (the common case: no deNoise point inside the batch)
   int denoise;                    // 1: drop entries whose count is exactly 1 (no new keys)
-  uint32_t *summary;              // [2*nregions]: T, c (relative to the region start; 0 = empty)
+  uint32_t *summary;              // [SHK_SUM_STRIDE*nregions]: T, c (relative to the region start; 0 = empty),
+                                  // new distinct, occurrences added, removed, new before hist_base
   unsigned long long *counters;   // 0 new distinct, 1 occurrences added, 2 removed, 3 new before hist_base
   unsigned long long *hist;       // [SHK_HIST_BINS]
   uint32_t *err;
@@ -136,7 +139,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   if (nblk_old > SHK_IMG_BLOCKS || ohi > SHK_IMG_SLOTS) {
     if (tid == 0) {
       atomicOr(A.err, SHK_E_OLD_EXTENT);
-      if (!WRITE) { A.summary[2 * r] = 0; A.summary[2 * r + 1] = 0; }
+      if (!WRITE) { for (int z = 0; z < SHK_SUM_STRIDE; z++) A.summary[SHK_SUM_STRIDE * r + z] = 0; }
     }
     return;
   }
@@ -172,7 +175,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
       if (ql >= nq) { atomicOr(A.err, SHK_E_CORRUPT); continue; }
       const uint32_t tag = (ql << 8) | (uint32_t)(key & 0xff);
       const uint32_t want = tag << SHK_CHUNK_BITS;
-      uint32_t h = (tag * 2654435761u) >> (32 - 12);
+      uint32_t h = (tag * 2654435761u) >> (32 - SHK_HCAP_LOG2);
       bool placed = false;
       for (uint32_t probe = 0; probe < SHK_HCAP; probe++) {
         uint32_t cur = hkey[h];
@@ -213,7 +216,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     uint32_t rc = (uint32_t)__popcll(rw);
     uint32_t rinc = shk_wave_incl_add(rc);
     uint32_t rbase = rinc - rc;
-    orrank[tid] = rbase;
+    if (tid < SHK_IMG_BLOCKS) orrank[tid] = rbase;
     if (tid == SHK_WAVE - 1) orrank[SHK_IMG_BLOCKS] = rinc;
     while (rw) {
       unsigned bit = (unsigned)(__ffsll((long long)rw) - 1);
@@ -226,7 +229,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   if (orrank[SHK_IMG_BLOCKS] != oorank[SHK_REGION_BLOCKS]) {
     if (tid == 0) {
       atomicOr(A.err, SHK_E_CORRUPT);
-      if (!WRITE) { A.summary[2 * r] = 0; A.summary[2 * r + 1] = 0; }
+      if (!WRITE) { for (int z = 0; z < SHK_SUM_STRIDE; z++) A.summary[SHK_SUM_STRIDE * r + z] = 0; }
     }
     return;
   }
@@ -289,10 +292,12 @@ __global__ void k_region_merge(ShkMergeArgs A) {
       const uint32_t ne = qoff[q + 1];
       uint32_t orem = 0, on = 0; uint64_t ocnt = 0;
       if (ohas) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt);
+      // head of the new list is kept in registers and reloaded only when it advances
+      uint32_t nrem = 256, nh = 0, nkey = 0;
+      if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
       while (ohas || ni < ne) {
-        uint32_t nrem = 256; uint32_t nh = 0;
-        if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
         uint32_t rem; uint64_t total; bool is_new = false; bool prot = false; uint32_t mc = 0;
+        bool adv = false;
         if (ohas && orem <= nrem) {
           rem = orem; total = ocnt;
           if (A.denoise) {
@@ -300,11 +305,16 @@ __global__ void k_region_merge(ShkMergeArgs A) {
             const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
             prot = (oimg[tb] >> (opos & 7)) & 1;
           }
-          if (orem == nrem) { total += hcnt[nh]; ni++; }
+          if (orem == nrem) { total += hcnt[nh]; adv = true; }
           opos += on;
           if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
         } else {
-          rem = nrem; total = hcnt[nh]; is_new = true; mc = hkey[nh] & (SHK_MAX_CHUNKS - 1); ni++;
+          rem = nrem; total = hcnt[nh]; is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); adv = true;
+        }
+        if (adv) {
+          ni++;
+          nrem = 256;
+          if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
         }
         if (A.denoise && total < 2 && !prot) { my_removed++; continue; }
         if (!WRITE && is_new) {
@@ -329,18 +339,18 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
 
   if (!WRITE) {
-    uint64_t t_added = shk_block_sum64(my_added, scratch64);
-    uint64_t t_new = shk_block_sum64(my_new, scratch64);
-    uint64_t t_removed = shk_block_sum64(my_removed, scratch64);
-    uint64_t t_before = shk_block_sum64(my_before, scratch64);
+    // per-region counts are < 2^32 (a batch holds < 2^32 keys): two packed sums
+    const uint64_t s1 = shk_block_sum64((my_added << 32) | my_new, scratch64);
+    const uint64_t s2 = shk_block_sum64((my_removed << 32) | my_before, scratch64);
+    const uint64_t t_added = s1 >> 32, t_new = s1 & 0xffffffffu, t_removed = s2 >> 32, t_before = s2 & 0xffffffffu;
     if (tid == 0) {
-      A.summary[2 * r] = (uint32_t)tot.a;
-      A.summary[2 * r + 1] = tot.b > 0 ? (uint32_t)tot.b : 0;
+      // per-region statistics go to memory; k_region_scan_c adds them up (one atomic per
+      // tile instead of millions on the same four words)
+      uint32_t *sm = A.summary + (size_t)SHK_SUM_STRIDE * r;
+      sm[0] = (uint32_t)tot.a;
+      sm[1] = tot.b > 0 ? (uint32_t)tot.b : 0;
+      sm[2] = (uint32_t)t_new; sm[3] = (uint32_t)t_added; sm[4] = (uint32_t)t_removed; sm[5] = (uint32_t)t_before;
       if (tot.a > 0xFFFF) atomicOr(A.err, SHK_E_RUN_TOO_LONG);
-      if (t_new) atomicAdd(&A.counters[0], (unsigned long long)t_new);
-      if (t_added) atomicAdd(&A.counters[1], (unsigned long long)t_added);
-      if (t_removed) atomicAdd(&A.counters[2], (unsigned long long)t_removed);
-      if (t_before) atomicAdd(&A.counters[3], (unsigned long long)t_before);
       if (s_fail) atomicOr(A.err, s_fail);
     }
     if (tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
@@ -398,21 +408,26 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     if (ohas) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt);
     uint32_t wp = rstart[q];
     uint8_t enc[12];
+    uint32_t nrem = 256, nh = 0;
+    if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
     while (ohas || ni < ne) {
-      uint32_t nrem = 256; uint32_t nh = 0;
-      if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
-      uint32_t rem; uint64_t total; bool prot = false;
+      uint32_t rem; uint64_t total; bool prot = false; bool adv = false;
       if (ohas && orem <= nrem) {
         rem = orem; total = ocnt;
         if (A.denoise) {
           const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
           prot = (oimg[tb] >> (opos & 7)) & 1;
         }
-        if (orem == nrem) { total += hcnt[nh]; ni++; }
+        if (orem == nrem) { total += hcnt[nh]; adv = true; }
         opos += on;
         if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
       } else {
-        rem = nrem; total = hcnt[nh]; ni++;
+        rem = nrem; total = hcnt[nh]; adv = true;
+      }
+      if (adv) {
+        ni++;
+        nrem = 256;
+        if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
       }
       if (A.denoise && total < 2 && !prot) continue;
       const unsigned n = shk_enc_write(enc, rem, total);
@@ -444,16 +459,30 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   // neighbouring regions' runs, so they are OR-ed in atomically (B was zeroed).
   uint8_t *tb = A.tabB + b0 * SHK_BLOCK_BYTES;
   if (A.ablate & 8) return;
-  for (uint32_t i = tid; i < nown * 9; i += nthr) {
+  // When no earlier region spills into this one, the own blocks are written whole with
+  // dword stores (a full region's own blocks are 356 contiguous, 4-byte aligned bytes).
+  uint32_t vblk = nown;
+  if (new_any && out_lo == 0 && (nown * SHK_BLOCK_BYTES) % 4 == 0) {
+    vblk = 0;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(nimg);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(tb);
+    for (uint32_t i = tid; i < nown * SHK_BLOCK_BYTES / 4; i += nthr) dst[i] = src[i];
+  }
+  // the blocks before vblk: offset byte + occupieds always, slots/runends only where owned
+  for (uint32_t i = tid; i < vblk * 9; i += nthr) {
     const uint32_t blk = i / 9, byte = i % 9;
     tb[blk * SHK_BLOCK_BYTES + byte] = nimg[blk * SHK_BLOCK_BYTES + byte];
   }
   if (out_hi > out_lo) {
-    for (uint32_t p = out_lo + tid; p < out_hi; p += nthr) tb[shk_img_slot_off(p)] = nimg[shk_img_slot_off(p)];
+    // slots [out_lo, out_hi) minus what the dword stores covered ([vblk*64, nown*64))
+    const uint32_t va = vblk * 64, vb = nown * 64;
+    for (uint32_t p = out_lo + tid; p < out_hi; p += nthr)
+      if (p < va || p >= vb || vblk == nown) tb[shk_img_slot_off(p)] = nimg[shk_img_slot_off(p)];
     const uint32_t m0 = out_lo >> 3, m1 = (out_hi - 1) >> 3;
     for (uint32_t m = m0 + tid; m <= m1; m += nthr) {
       const uint32_t bo = (m >> 3) * SHK_BLOCK_BYTES + SHK_OFF_RUN + (m & 7);
       const uint8_t v = nimg[bo];
+      if (vblk < nown && (m >> 3) >= vblk && (m >> 3) < nown) continue;  // written by the vector stores
       if (m == m0 || m == m1) {
         if (v) {
           uint8_t *addr = tb + bo;
@@ -469,34 +498,77 @@ __global__ void k_region_merge(ShkMergeArgs A) {
 }
 
 // ---------------------------------------------------------------- free pointers
-// fin[r+1] = max(fin[r] + T_r, region start + c_r). One workgroup walks all regions.
-__global__ void k_region_scan(const uint32_t *summary, uint32_t nregions, uint64_t xnslots, uint64_t *fin,
-                              uint32_t *err) {
+// fin[r+1] = max(fin[r] + T_r, region start + c_r), as a 3-launch scan over tiles of regions.
+#define SHK_RSCAN_TILE 4096
+__device__ __forceinline__ ShkMP shk_region_mp(const uint32_t *summary, uint32_t r, uint32_t nregions) {
+  ShkMP m; m.a = 0; m.b = SHK_NEG_INF;
+  if (r < nregions) {
+    m.a = summary[(size_t)SHK_SUM_STRIDE * r];
+    const uint32_t c = summary[(size_t)SHK_SUM_STRIDE * r + 1];
+    if (c) m.b = (long long)r * SHK_REGION + c;
+  }
+  return m;
+}
+// a: one workgroup per tile -> the tile's composed function
+__global__ void k_region_scan_a(const uint32_t *summary, uint32_t nregions, long long *tile_a, long long *tile_b) {
+  __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
+  const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
+  const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
+  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, base + threadIdx.x * per + j, nregions));
+  ShkMP tot;
+  shk_block_exscan_mp(mine, &tot, mpa, mpb);
+  if (threadIdx.x == 0) { tile_a[blockIdx.x] = tot.a; tile_b[blockIdx.x] = tot.b; }
+}
+// b: one workgroup: free pointer at every tile start
+__global__ void k_region_scan_b(const long long *tile_a, const long long *tile_b, uint32_t ntiles, long long *tile_f) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   __shared__ long long carry_s;
-  if (threadIdx.x == 0) { carry_s = 0; fin[0] = 0; }
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < nregions; base += blockDim.x) {
-    const uint32_t r = base + threadIdx.x;
+  for (uint32_t b0 = 0; b0 < ntiles; b0 += blockDim.x) {
+    const uint32_t t = b0 + threadIdx.x;
     ShkMP m; m.a = 0; m.b = SHK_NEG_INF;
-    if (r < nregions) {
-      m.a = summary[2 * r];
-      const uint32_t c = summary[2 * r + 1];
-      if (c) m.b = (long long)r * SHK_REGION + c;
-    }
+    if (t < ntiles) { m.a = tile_a[t]; m.b = tile_b[t]; }
     ShkMP tot;
     ShkMP pre = shk_block_exscan_mp(m, &tot, mpa, mpb);
     const long long carry = carry_s;
-    if (r < nregions) {
-      const long long fi = shk_mp_apply(pre, carry);
-      const long long fo = shk_mp_apply(m, fi);
-      fin[r + 1] = (uint64_t)fo;
-      if (m.a > 0 && fo - (long long)r * SHK_REGION > SHK_IMG_SLOTS) atomicOr(err, SHK_E_NEW_EXTENT);
-      if ((uint64_t)fo > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
-    }
+    if (t < ntiles) tile_f[t] = shk_mp_apply(pre, carry);
     __syncthreads();
     if (threadIdx.x == 0) carry_s = shk_mp_apply(tot, carry);
     __syncthreads();
+  }
+}
+// c: one workgroup per tile: fin[] for its regions + the capacity checks
+__global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, const long long *tile_f, uint64_t xnslots,
+                                uint64_t *fin, unsigned long long *counters, uint32_t *err) {
+  __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
+  __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
+  const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
+  const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
+  const uint32_t r0 = base + threadIdx.x * per;
+  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, r0 + j, nregions));
+  ShkMP tot;
+  ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
+  long long f = shk_mp_apply(pre, tile_f[blockIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) fin[0] = 0;
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t r = r0 + j;
+    if (r >= nregions) break;
+    const ShkMP m = shk_region_mp(summary, r, nregions);
+    f = shk_mp_apply(m, f);
+    fin[r + 1] = (uint64_t)f;
+    if (m.a > 0 && f - (long long)r * SHK_REGION > SHK_IMG_SLOTS) atomicOr(err, SHK_E_NEW_EXTENT);
+    if ((uint64_t)f > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
+  }
+  // statistics of this tile's regions
+  for (int z = 0; z < 4; z++) {
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < per; j++)
+      if (r0 + j < nregions) v += summary[(size_t)SHK_SUM_STRIDE * (r0 + j) + 2 + z];
+    const uint64_t t = shk_block_sum64(v, scratch64);
+    if (threadIdx.x == 0 && t) atomicAdd(&counters[z], (unsigned long long)t);
   }
 }
 

