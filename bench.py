@@ -236,6 +236,9 @@ def main():
     torch.cuda.synchronize()
 
     hb = qb + 8
+    from shk import dist as shkdist
+    sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
+    counted_global = [0]
     shard_shift = (qb - int(math.log2(world))) + 8
     rounds_left = nd
     counted = 0
@@ -253,31 +256,20 @@ def main():
             return
         dp, nw = ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
         words = torch.as_tensor(_CAI(dp, nw), device=device)
-        key = words & ((1 << hb) - 1)
-        owner = key >> shard_shift
-        order = torch.argsort(owner)
-        send = (key[order]).contiguous()                      # chunk index dropped: rounds fire per step here
-        send_counts = torch.bincount(owner, minlength=world)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        recv = torch.empty((sum(rc),), dtype=torch.int64, device=device)
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+        # global chunk order: the ranks' parts interleave like the reference's file queue (CQF_mt.h:828-830)
+        words = (words & ((1 << hb) - 1)) | (((words >> hb) * world + rank) << hb)
+        recv = shkdist.route_words(words, hb, qb, world, device)
         torch.cuda.synchronize()
-        st = ctx.count_words(recv.data_ptr(), recv.numel(), 1)
-        counted += st["kmers"]
-        # deNoise at step granularity: global distinct count against the trigger
-        if rounds_left > 0:
-            nd_local = torch.tensor([ctx.totals().ndistinct], dtype=torch.int64, device=device)
-            dist.all_reduce(nd_local)
-            if int(nd_local.item()) >= trigger:
-                removed_total += ctx.denoise()
-                rounds_left -= 1
-                rounds_fired += 1
+        ctx.stage_words(recv.data_ptr(), recv.numel())
+        r = shkdist.sharded_count(ctx, sstate, len(offs) * world)
+        counted_global[0] += r["kmers"]
+        removed_total += r["removed"]
+        rounds_fired += r["denoise_rounds"]
 
     for s in range(args.warmup):
         step(s)
     counted = 0
+    counted_global[0] = 0
     removed_total = 0
     rounds_fired = 0
     if args.ablate:
@@ -299,9 +291,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cc = torch.tensor([counted], dtype=torch.int64, device=device)
-        dist.all_reduce(cc)
-        counted = int(cc.item())
+        counted = counted_global[0]      # already the whole-job count (all-reduced inside sharded_count)
 
     if rank == 0:
         # dominant kernel by accumulated device time

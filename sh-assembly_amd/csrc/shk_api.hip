@@ -71,6 +71,7 @@ struct shk_ctx {
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> evpool;
   uint32_t last_err_bits;
+  int staged;                   // which d_words[] holds the partitioned words of shk_stage_words
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libshk: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return SHK_ERR_HIP; } } while (0)
@@ -557,6 +558,43 @@ extern "C" int shk_count_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwo
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, &st);
   if (stats) *stats = st;
+  return finish(c, rc);
+}
+
+extern "C" int shk_stage_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwords) {
+  if (!c || (!d_words && nwords)) return SHK_ERR_ARG;
+  if (nwords > c->cfg.max_batch_keys) return SHK_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->dev));
+  if (d_words != c->d_words[0] && nwords)
+    HIPCHK(hipMemcpyAsync(c->d_words[0], d_words, nwords * 8, hipMemcpyDeviceToDevice, c->stream));
+  c->h_pinned[43] = nwords;
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
+  int dst = 0;
+  int rc = partition_stage(c, 0, nwords, &dst);
+  c->staged = dst;
+  return finish(c, rc);
+}
+
+extern "C" int shk_stage_summary(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t hist_base, uint32_t hist_shift,
+                                 int want_hist, shk_summary *out) {
+  if (!c || !out || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  MergeOut o;
+  int rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist);
+  prof_collect(c);
+  if (rc) return rc;
+  out->new_distinct = o.newd; out->added = o.added; out->removed = o.removed; out->before = o.before;
+  for (int i = 0; i < SHK_HIST_BINS; i++) out->hist[i] = o.hist[i];
+  out->err_bits = o.err; out->reserved = 0;
+  return SHK_OK;
+}
+
+extern "C" int shk_stage_commit(shk_ctx *c, uint32_t lo, uint32_t hi, const shk_summary *s) {
+  if (!c || !s || hi < lo) return SHK_ERR_ARG;
+  if (s->err_bits) return map_err_bits(s->err_bits);
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = merge_write(c, c->d_words[c->staged], lo, hi, 0);
+  if (!rc) { c->ndistinct += s->new_distinct; c->nelts += s->added; }
   return finish(c, rc);
 }
 

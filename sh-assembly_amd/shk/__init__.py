@@ -37,6 +37,16 @@ class Totals(C.Structure):
                 ("nblocks", C.c_uint64), ("table_bytes", C.c_uint64), ("free_pointer", C.c_uint64)]
 
 
+class Summary(C.Structure):
+    _fields_ = [("new_distinct", C.c_uint64), ("added", C.c_uint64), ("removed", C.c_uint64), ("before", C.c_uint64),
+                ("hist", C.c_uint64 * 32), ("err_bits", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+SOFT_BITS = 0x0A
+HASH_FULL_BIT = 0x04
+HIST_BINS = 32
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("ms", C.c_double)]
 
@@ -47,7 +57,8 @@ class ShkError(RuntimeError):
         self.code = code
 
 
-EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_denoise",
+EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_stage_words",
+           "shk_stage_summary", "shk_stage_commit", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
            "shk_last_error_bits"]
@@ -71,6 +82,9 @@ def load(path=None):
     L.shk_count_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(BatchStats)]
     L.shk_hash_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(vp), pu64]
     L.shk_count_words.argtypes = [vp, vp, u64, u32, C.POINTER(BatchStats)]
+    L.shk_stage_words.argtypes = [vp, vp, u64]
+    L.shk_stage_summary.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
+    L.shk_stage_commit.argtypes = [vp, u32, u32, C.POINTER(Summary)]
     L.shk_denoise.argtypes = [vp, pu64]
     L.shk_stats.argtypes = [vp, C.POINTER(Totals)]
     L.shk_header.argtypes = [vp, C.c_char_p]
@@ -161,6 +175,23 @@ class Context:
         self._chk(self.L.shk_count_words(self.h, C.c_void_p(int(d_words) if d_words else 0), nwords, nchunks,
                                          C.byref(st)))
         return st.as_dict()
+
+    def stage_words(self, d_words, nwords):
+        self._chk(self.L.shk_stage_words(self.h, C.c_void_p(int(d_words) if d_words else 0), nwords))
+
+    def stage_summary(self, lo, hi, hist_base=0, hist_shift=0, want_hist=False):
+        s = Summary()
+        self._chk(self.L.shk_stage_summary(self.h, lo, hi, hist_base, hist_shift, 1 if want_hist else 0, C.byref(s)))
+        return s
+
+    def stage_commit(self, lo, hi, summary):
+        self._chk(self.L.shk_stage_commit(self.h, lo, hi, C.byref(summary)))
+
+    def error_for_bits(self, bits):
+        """raise the library's error for raw kernel flag bits (commit of an empty Summary does the mapping)"""
+        s = Summary()
+        s.err_bits = bits
+        self._chk(self.L.shk_stage_commit(self.h, 0, 0, C.byref(s)))
 
     def denoise(self):
         r = C.c_uint64()

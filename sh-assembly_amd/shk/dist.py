@@ -1,0 +1,123 @@
+"""Quotient-range sharding over several GPUs (one process per GPU, torch.distributed).
+
+`sharded_count` is the multi-GPU form of csrc/shk_api.hip `merge_stage`: every rank stages the
+key words it OWNS (routing is the caller's all-to-all), and the ranks take the deNoise decision
+together on all-reduced statistics, so a round fires after the same global chunk on every
+shard -- the chunk at which the whole filter's distinct count reaches the trigger
+(cqf/CQF_mt.h:837, 860-869). Works with RCCL ("nccl") on GPUs and with gloo on the CPU."""
+import torch
+import torch.distributed as dist
+
+from . import HASH_FULL_BIT, HIST_BINS, SOFT_BITS, ShkError
+
+
+class ShardState:
+    """filter-wide bookkeeping kept identically on every rank (runtime->ndistinct_elts etc.)"""
+
+    def __init__(self, trigger, rounds_left, device):
+        self.trigger, self.rounds_left, self.rounds_done = trigger, rounds_left, 0
+        self.ndistinct = 0          # whole filter
+        self.nelts = 0
+        self.device = device
+
+
+def _allreduce(vals, device, op=None):
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]
+
+
+def _summary(ctx, st, lo, hi, base, shift, want_hist):
+    """local summary + reduction; returns (newd, before, hist[], hard_bits_any, hash_full_any, soft_any, local)"""
+    s = ctx.stage_summary(lo, hi, base, shift, want_hist)
+    red = _allreduce([s.new_distinct, s.before] + list(s.hist), st.device)
+    flags = _allreduce([s.err_bits & ~(SOFT_BITS | HASH_FULL_BIT) & 0xFFFFFFFF, s.err_bits & HASH_FULL_BIT,
+                        s.err_bits & SOFT_BITS], st.device, dist.ReduceOp.MAX)
+    return red[0], red[1], red[2:], flags[0], flags[1], flags[2], s
+
+
+def sharded_count(ctx, st, nchunks):
+    """insert the staged words of global chunks [0, nchunks); returns dict(kmers, new_distinct, removed, rounds)"""
+    out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
+    lo = 0
+    while lo < nchunks:
+        hi = nchunks - 1
+        watch = st.rounds_left > 0
+        while True:
+            span = hi - lo + 1
+            shift = 0
+            while ((span + (1 << shift) - 1) >> shift) > HIST_BINS:
+                shift += 1
+            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, False)
+            if hard:
+                ctx.error_for_bits(hard)
+            if hfull:
+                if hi == lo:
+                    ctx.error_for_bits(HASH_FULL_BIT)
+                hi = lo + (hi - lo) // 2
+                continue
+            break
+        fire = False
+        if watch and st.ndistinct + newd >= st.trigger:
+            base = lo
+            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, True)
+            if hard:
+                ctx.error_for_bits(hard)
+            while True:
+                run = st.ndistinct + before
+                b = 0
+                while b < HIST_BINS:
+                    if run + hist[b] >= st.trigger:
+                        break
+                    run += hist[b]
+                    b += 1
+                b = min(b, HIST_BINS - 1)
+                b_lo = base + (b << shift)
+                b_hi = min(b_lo + (1 << shift) - 1, hi)
+                if shift == 0:
+                    hi = b_lo
+                    break
+                span2 = b_hi - b_lo + 1
+                shift = 0
+                while ((span2 + (1 << shift) - 1) >> shift) > HIST_BINS:
+                    shift += 1
+                base = b_lo
+                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, b_hi, base, shift, True)
+                if hard:
+                    ctx.error_for_bits(hard)
+            fire = True
+            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False)
+        if hard or hfull or soft:
+            ctx.error_for_bits(hard | hfull | soft)
+        ctx.stage_commit(lo, hi, loc)
+        added = _allreduce([loc.added], st.device)[0]
+        st.ndistinct += newd
+        st.nelts += added
+        out["kmers"] += added
+        out["new_distinct"] += newd
+        if fire:
+            st.rounds_left -= 1
+            st.rounds_done += 1
+            removed = _allreduce([ctx.denoise()], st.device)[0]
+            st.ndistinct -= removed
+            st.nelts -= removed
+            out["removed"] += removed
+            out["denoise_rounds"] += 1
+        lo = hi + 1
+    return out
+
+
+def route_words(words, hb, qb, world, device):
+    """bin key words by owner = top log2(world) bits of the quotient and exchange them (all-to-all)"""
+    shift = hb - (world.bit_length() - 1)
+    key = words & ((1 << hb) - 1)
+    owner = key >> shift
+    order = torch.argsort(owner)
+    send = words[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    recv = torch.empty((sum(rc),), dtype=words.dtype, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+    return recv
