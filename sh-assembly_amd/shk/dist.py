@@ -107,8 +107,14 @@ def sharded_count(ctx, st, nchunks):
     return out
 
 
+ROUTE_PIECE = 1 << 25   # elements per peer per exchange (256 MB of key words)
+
+
 def route_words(words, hb, qb, world, device):
-    """bin key words by owner = top log2(world) bits of the quotient and exchange them (all-to-all)"""
+    """bin key words by owner = top log2(world) bits of the quotient and exchange them.
+    The exchange runs as a sequence of all-to-alls of at most ROUTE_PIECE words per peer: one
+    RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only its first
+    832 MB on this stack (tools/dbg_dist.py), and bounded pieces also bound the staging memory."""
     shift = hb - (world.bit_length() - 1)
     key = words & ((1 << hb) - 1)
     owner = key >> shift
@@ -119,5 +125,20 @@ def route_words(words, hb, qb, world, device):
     dist.all_to_all_single(recv_counts, send_counts)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     recv = torch.empty((sum(rc),), dtype=words.dtype, device=device)
-    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+    mx = _allreduce([max(sc + rc)], device, dist.ReduceOp.MAX)[0]
+    soff = [sum(sc[:p]) for p in range(world)]
+    roff = [sum(rc[:p]) for p in range(world)]
+    for r0 in range(0, max(mx, 1), ROUTE_PIECE):
+        ins = [send[soff[p] + min(r0, sc[p]): soff[p] + min(r0 + ROUTE_PIECE, sc[p])] for p in range(world)]
+        outs = [recv[roff[p] + min(r0, rc[p]): roff[p] + min(r0 + ROUTE_PIECE, rc[p])] for p in range(world)]
+        if world == 1:
+            outs[0].copy_(ins[0])
+            continue
+        isz, osz = [int(x.numel()) for x in ins], [int(x.numel()) for x in outs]
+        piece = torch.empty((sum(osz),), dtype=words.dtype, device=device)
+        dist.all_to_all_single(piece, torch.cat(ins), output_split_sizes=osz, input_split_sizes=isz)
+        o = 0
+        for p in range(world):
+            outs[p].copy_(piece[o:o + osz[p]])
+            o += osz[p]
     return recv
