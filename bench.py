@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=2_000_000)
+    ap.add_argument("--reads-per-step", type=int, default=8_000_000)
     ap.add_argument("--genome", type=int, default=100_000_000)
     ap.add_argument("--qb", type=int, default=0, help="override the filter size (default: README sizing)")
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
@@ -214,10 +214,13 @@ def main():
 
     K, L, ERR = 47, 150, 0.00234
     N_README, n_README = 16506371070, 119157843            # README.md:90-91
-    qb, nd, trigger = sizing(K, n_README, N_README, ERR)
+    R = args.reads_per_step
+    # README sizing; when the planned run presents more k-mers than the README's N (weak
+    # scaling over several GPUs) the same formulas are applied to the planned total
+    N_plan = max(N_README, world * (args.steps + args.warmup) * R * (L - K + 1))
+    qb, nd, trigger = sizing(K, n_README, N_plan, ERR)
     if args.qb:
         qb = args.qb
-    R = args.reads_per_step
     rec = 2 * L + NAME_W + 6
     kmers_per_read = L - K + 1
     offs, lens = chunk_table(R, rec)
@@ -309,8 +312,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C.elegans-like synthetic reads (G=%d, L=150, e=0.00234), k=47, CQF qb=%d hb=%d "
-                                   "(README.md:98 sizing), %d reads/step/GPU, 8 MiB chunks, deNoise rounds=%d trigger=%d"
-                                   % (args.genome, qb, hb, R, nd, trigger),
+                                   "(README.md:98 sizing, N=%d), %d reads/step/GPU, 8 MiB chunks, deNoise rounds=%d trigger=%d"
+                                   % (args.genome, qb, hb, N_plan, R, nd, trigger),
                        "kmers_per_step_per_gpu": R * kmers_per_read, "denoise_rounds_fired": rounds_fired,
                        "removed": removed_total, "parallelism": "quotient-range shards x%d" % world},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

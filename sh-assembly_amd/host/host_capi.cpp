@@ -1,0 +1,27 @@
+// C entry points over the host-only pieces (chunker, sizing) so that the CPU test-suite can
+// check them against the oracle without a GPU (libshkhost.so, built with g++).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+#include "fastq_chunker.hpp"
+#include "sizing.hpp"
+
+extern "C" {
+// sizes of the parts getDataChunk hands out for a list of files (round robin), 0 = plain, 1 = gzip
+uint64_t shkh_chunk_sizes(const char **paths, int nfiles, int mode, uint64_t part_size, uint32_t overhead, uint64_t *sizes,
+                          uint64_t cap) {
+  std::vector<std::string> f(paths, paths + nfiles);
+  shk::seqFile_batch b(f, shk::FASTQ, mode ? shk::GZIP : shk::TEXT, part_size, overhead);
+  shk::chunk c;
+  uint64_t n = 0;
+  while (b.getDataChunk(c)) { if (n < cap) sizes[n] = c.get_size(); n++; free(c.get_reads()); }
+  return n;
+}
+void shkh_size_filter(int K, uint64_t n_true, uint64_t N_total, double alpha, int num_denoise, double fr, uint64_t *out) {
+  shk::Sizing s = shk::size_filter(K, n_true, N_total, alpha, "", num_denoise, fr);
+  out[0] = s.qb; out[1] = s.hb; out[2] = (uint64_t)s.num_deNoise; out[3] = s.n_distinct_elts_for_DeNoise;
+  out[4] = s.num_true_kmers; out[5] = s.num_false_kmers; out[6] = (uint64_t)s.lower_bound; out[7] = (uint64_t)s.upper_bound;
+}
+}

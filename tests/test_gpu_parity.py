@@ -60,3 +60,62 @@ def test_denoise_schedule_matches_oracle(qb, k, trigger, nd, endd, ml):
     assert ctx.blocks() == q.blocks()
     ctx.close()
     q.free()
+
+
+def test_cli_reproduces_golden_cqf(tmp_path):
+    """sh-assembly_amd/bin/CQF-deNoise (reference flags + test hooks for the small part
+    geometry of the fixtures) writes the .cqf files the REFERENCE build wrote for
+    tests/golden (fastq_builds.json)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "sh-assembly_amd", "bin", "CQF-deNoise")
+    assert os.path.exists(exe), "build with make -C sh-assembly_amd"
+    fx = json.load(open(os.path.join(G, "fastq_builds.json")))
+    for b in fx["builds"]:
+        c = b["cfg"]
+        lst = tmp_path / "files.txt"
+        # the list is resolved relative to its own directory (src/CQF-deNoise.cpp:59-81)
+        for f in c["files"]:
+            dst = tmp_path / f
+            if not dst.exists():
+                dst.write_bytes(open(os.path.join(G, f), "rb").read())
+        lst.write_text("\n".join(c["files"]) + "\n")
+        out = str(tmp_path / "out.cqf")
+        cmd = [exe, "-k", str(c["k"]), "-n", "6000", "-N", "100000", "-e", "0.01", "-f", "f", "-i", str(lst), "-o", out,
+               "--deNoise", str(c["nd"]), "--qb", str(c["qb"]), "--trigger", str(min(c["trigger"], 1 << 62)),
+               "--part-size", str(c["ps"]), "--overhead", str(c["ov"]), "--min-denoise-len", str(c["ml"])]
+        if c["end"]:
+            cmd.append("--endDeNoise")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == open(os.path.join(G, b["cqf"]), "rb").read(), (c, r.stderr[-400:])
+
+
+def test_lookup_and_traveled_marks():
+    """k_lookup against the oracle: counts, is_traveled, set_traveled (twice), table bytes after"""
+    import random
+    qb, k = 17, 31
+    g = synth.make_genome(20000, 3)
+    fq = synth.make_fastq(g, 3000, 100, 0.01, seed=5, n_frac=0.02)
+    offs, lens = chunks_by_records(fq, 500)
+    ctx = _ctx(qb=qb, k=k, max_batch_bytes=len(fq) + 1024, max_batch_keys=3000 * 100)
+    ctx.count_chunks(fq, offs, lens)
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    rnd = random.Random(1)
+    present = [kc[0] for kc in q.dump()]
+    keys = rnd.sample(present, 2000) + [rnd.randrange(1 << (qb + 8)) for _ in range(2000)]
+    cnt, _ = ctx.lookup(keys, mode=2)
+    assert cnt == [q.count(x) for x in keys]
+    c0, t0 = ctx.lookup(keys, mode=0)
+    assert t0 == [q.count_is_traveled(x)[0] for x in keys]
+    sub = keys[:1500:3] + keys[2000:2300]
+    _, t1 = ctx.lookup(sub, mode=1)
+    exp1 = [q.count_set_traveled(x)[0] for x in sub]
+    _, t2 = ctx.lookup(sub, mode=1)
+    exp2 = [q.count_set_traveled(x)[0] for x in sub]
+    assert (t1, t2) == (exp1, exp2)
+    assert ctx.blocks() == q.blocks()
+    ctx.close()
+    q.free()
