@@ -32,7 +32,7 @@ static void usage(const char *argv0) {
        << "  -f [ --format ] arg      format of the input: g(gzip); b(bzip2); f(plain fastq)\n"
        << "  -i [ --input ] arg       a file containing a list of read file name(s), should be in the same directory as the fastq file(s)\n"
        << "  -o [ --output ] arg      output file name\n"
-       << "  (test hooks, not in the reference: --qb N --trigger N --part-size N --overhead N --min-denoise-len N --device N)\n\n";
+       << "  (test hooks, not in the reference: --qb N --trigger N --rounds N --part-size N --overhead N --min-denoise-len N --device N)\n\n";
 }
 
 int main(int argc, char *argv[]) {
@@ -42,7 +42,7 @@ int main(int argc, char *argv[]) {
   string errorProfile, flist, output_file;
   bool end_deNoise = false, have_n = false, have_N = false;
   char fmt = 0;
-  long long qb_override = -1, trigger_override = -1, part_size = 1LL << 23, overhead = 65535, min_len = 0;
+  long long qb_override = -1, trigger_override = -1, rounds_override = -1, part_size = 1LL << 23, overhead = 65535, min_len = 0;
   if (argc == 1) { usage(argv[0]); return 0; }
   for (int i = 1; i < argc; i++) {
     string a = argv[i];
@@ -68,6 +68,7 @@ int main(int argc, char *argv[]) {
     else if (name == "-o" || name == "--output") output_file = val();
     else if (name == "--qb") qb_override = atoll(val().c_str());
     else if (name == "--trigger") trigger_override = atoll(val().c_str());
+    else if (name == "--rounds") rounds_override = atoll(val().c_str());
     else if (name == "--part-size") part_size = atoll(val().c_str());
     else if (name == "--overhead") overhead = atoll(val().c_str());
     else if (name == "--min-denoise-len") min_len = atoll(val().c_str());
@@ -95,7 +96,7 @@ int main(int argc, char *argv[]) {
   uint64_t qb = qb_override > 0 ? (uint64_t)qb_override : sz.qb;
   uint64_t hb = qb + 8;
   uint64_t trigger = trigger_override >= 0 ? (uint64_t)trigger_override : sz.n_distinct_elts_for_DeNoise;
-  num_deNoise = sz.num_deNoise;
+  num_deNoise = rounds_override >= 0 ? (int)rounds_override : sz.num_deNoise;
   if (output_file.empty()) output_file = "k" + to_string(K) + ".t" + to_string(thread_num) + ".s" + to_string(qb) + ".ser";
 
   FILE_MODE ftype;

@@ -84,7 +84,7 @@ def test_cli_reproduces_golden_cqf(tmp_path):
         lst.write_text("\n".join(c["files"]) + "\n")
         out = str(tmp_path / "out.cqf")
         cmd = [exe, "-k", str(c["k"]), "-n", "6000", "-N", "100000", "-e", "0.01", "-f", "f", "-i", str(lst), "-o", out,
-               "--deNoise", str(c["nd"]), "--qb", str(c["qb"]), "--trigger", str(min(c["trigger"], 1 << 62)),
+               "--deNoise", str(c["nd"]), "--rounds", str(c["nd"]), "--qb", str(c["qb"]), "--trigger", str(min(c["trigger"], 1 << 62)),
                "--part-size", str(c["ps"]), "--overhead", str(c["ov"]), "--min-denoise-len", str(c["ml"])]
         if c["end"]:
             cmd.append("--endDeNoise")
