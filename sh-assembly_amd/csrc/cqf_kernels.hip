@@ -19,12 +19,13 @@
 
 #define SHK_EMPTY 0xFFFFFFFFu
 #define SHK_SUM_STRIDE 6
+#define SHK_RSCAN_TILE 4096
 
 struct ShkMergeArgs {
   const uint8_t *tabA;
   uint8_t *tabB;
   const uint64_t *finA;         // [nregions+1] free pointer at each region start of A
-  const uint64_t *finB;         // same for B (write pass input)
+  uint64_t *finB;               // same for B (write pass input; written by the single-launch rebuild)
   const uint64_t *words;        // keys sorted by region; null when there are none
   const uint64_t *region_base;  // [nregions+1] offsets into words
   uint64_t nslots, xnslots, nblocks;
@@ -39,6 +40,8 @@ struct ShkMergeArgs {
   unsigned long long *counters;   // 0 new distinct, 1 occurrences added, 2 removed, 3 new before hist_base
   unsigned long long *hist;       // [SHK_HIST_BINS]
   uint32_t *err;
+  unsigned long long *lb_agg;     // [nregions] look-back records of the single-launch rebuild (zeroed per launch)
+  unsigned long long *lb_incl;    // [nregions]
   uint32_t ablate;                // diagnostics only (SHK_ABLATE): skip phases to time them; results invalid
 };
 
@@ -99,8 +102,34 @@ __device__ __forceinline__ ShkMP shk_block_exscan_mp(ShkMP v, ShkMP *total, long
   return res;
 }
 
-template <bool WRITE>
-__global__ void k_region_merge(ShkMergeArgs A) {
+// ---- one merged entry of a run: fast paths for the common small counts
+__device__ __forceinline__ unsigned shk_enc_len_fast(unsigned rem, uint64_t total) {
+  if (total <= 1) return (unsigned)total;
+  if (total <= 128) return 2u + ((unsigned)(total - 1) > rem ? 1u : 0u);
+  return shk_enc_len(rem, total);
+}
+// decode_counter (gqf.c:1259-1299) on the block image with a fast path for counts <= 128
+__device__ __forceinline__ unsigned shk_img_dec_fast(const uint8_t *img, unsigned pos, unsigned run_end, unsigned *rem_out,
+                                                     uint64_t *count) {
+  const unsigned rem = img[shk_img_slot_off(pos)];
+  *rem_out = rem;
+  if (pos == run_end) { *count = 1; return 1; }
+  const unsigned d = img[shk_img_slot_off(pos + 1)];
+  if (d > rem) { *count = 1; return 1; }
+  if (d != 0 && d < 0x80) { *count = (uint64_t)d + 1; return 2; }
+  return shk_img_dec(img, pos, run_end, rem_out, count);
+}
+
+// MODE 0: summary (lengths + statistics). MODE 1: write pass of the two-launch scheme
+// (free pointers come from k_region_scan_*). MODE 2: single launch -- the wave obtains its
+// free pointer by looking back at the regions before it (see k_region_merge docs below).
+#define SHK_STAGE_PER_LANE 40   // bytes of encoded run kept per lane between the length pass and placement
+#define SHK_LB_VALID 0x80000000u
+#define SHK_LB_INCL (1ULL << 63)
+
+template <int MODE>
+__global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs A) {
+  constexpr bool WRITE = MODE != 0;
   __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
   __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch
   __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
@@ -110,16 +139,16 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   __shared__ uint16_t rstart[SHK_REGION];
   __shared__ __attribute__((aligned(16))) uint8_t oimg[SHK_IMG_BYTES + 16];
   __shared__ __attribute__((aligned(16))) uint8_t nimg[SHK_IMG_BYTES + 16];
+  __shared__ uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_PER_LANE];
   __shared__ uint64_t oocc[SHK_REGION_BLOCKS];
+  __shared__ uint64_t orunw[SHK_IMG_BLOCKS];
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
   __shared__ uint32_t orrank[SHK_IMG_BLOCKS + 1];
   __shared__ uint32_t lhist[SHK_HIST_BINS];
-  __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
-  __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
-  __shared__ uint32_t scratch32[SHK_MAX_WAVES + 1];
   __shared__ uint32_t s_fail;
 
-  const unsigned tid = threadIdx.x, nthr = blockDim.x;
+  const unsigned tid = threadIdx.x;
+  constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave
   const uint32_t r = blockIdx.x;
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -135,17 +164,15 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   uint32_t nblk_old = old_any ? (ohi + 63) / 64 : 0;
   if (nblk_old < nown) nblk_old = nown;
   if (tid == 0) s_fail = 0;
-  __syncthreads();
+  bool fatal = false;
   if (nblk_old > SHK_IMG_BLOCKS || ohi > SHK_IMG_SLOTS) {
-    if (tid == 0) {
-      atomicOr(A.err, SHK_E_OLD_EXTENT);
-      if (!WRITE) { for (int z = 0; z < SHK_SUM_STRIDE; z++) A.summary[SHK_SUM_STRIDE * r + z] = 0; }
-    }
-    return;
+    if (tid == 0) atomicOr(A.err, SHK_E_OLD_EXTENT);
+    fatal = true;
+    nblk_old = nown;
   }
   if (b0 + nblk_old > A.nblocks) nblk_old = (uint32_t)(A.nblocks - b0);
 
-  // ---- stage the old bytes (dword copies; the region's first byte is 16-B aligned)
+  // ---- stage the old bytes (dword copies; the region's first byte is 4-byte aligned)
   {
     const uint32_t nbytes = nblk_old * SHK_BLOCK_BYTES;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
@@ -162,8 +189,8 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   __syncthreads();
 
   // ---- fold this region's new keys into the LDS hash
-  uint64_t my_added = 0;
-  if (A.words && !(A.ablate & 1)) {
+  uint32_t my_added = 0;
+  if (A.words && !fatal) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
     const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
     for (uint64_t i = kb + tid; i < ke; i += nthr) {
@@ -194,17 +221,16 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   __syncthreads();
 
   // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
-  if (tid < SHK_WAVE) {
-    // wave 0: two 64-wide prefix popcounts
+  {
     uint64_t ow = 0;
     if (tid < nown) ow = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_OCC);
     if (tid < SHK_REGION_BLOCKS) oocc[tid] = ow;
-    uint32_t pc = (uint32_t)__popcll(ow);
-    uint32_t inc = shk_wave_incl_add(pc);
+    const uint32_t pc = (uint32_t)__popcll(ow);
+    const uint32_t inc = shk_wave_incl_add(pc);
     if (tid < SHK_REGION_BLOCKS) oorank[tid] = inc - pc;
     if (tid == SHK_REGION_BLOCKS - 1) oorank[SHK_REGION_BLOCKS] = inc;
     uint64_t rw = 0;
-    if (old_any && tid < nblk_old) {
+    if (old_any && !fatal && tid < nblk_old) {
       rw = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_RUN);
       const uint32_t s0 = tid * 64;
       if (s0 + 64 <= olo || s0 >= ohi) rw = 0;
@@ -213,48 +239,48 @@ __global__ void k_region_merge(ShkMergeArgs A) {
         if (ohi < s0 + 64) rw &= ((1ULL << (ohi - s0)) - 1);
       }
     }
-    uint32_t rc = (uint32_t)__popcll(rw);
-    uint32_t rinc = shk_wave_incl_add(rc);
-    uint32_t rbase = rinc - rc;
-    if (tid < SHK_IMG_BLOCKS) orrank[tid] = rbase;
+    const uint32_t rc = (uint32_t)__popcll(rw);
+    const uint32_t rinc = shk_wave_incl_add(rc);
+    if (tid < SHK_IMG_BLOCKS) { orrank[tid] = rinc - rc; orunw[tid] = rw; }
     if (tid == SHK_WAVE - 1) orrank[SHK_IMG_BLOCKS] = rinc;
-    while (rw) {
-      unsigned bit = (unsigned)(__ffsll((long long)rw) - 1);
-      rw &= rw - 1;
-      if (rbase < SHK_REGION) orend[rbase] = (uint16_t)(tid * 64 + bit);
-      rbase++;
-    }
   }
   __syncthreads();
-  if (orrank[SHK_IMG_BLOCKS] != oorank[SHK_REGION_BLOCKS]) {
-    if (tid == 0) {
-      atomicOr(A.err, SHK_E_CORRUPT);
-      if (!WRITE) { for (int z = 0; z < SHK_SUM_STRIDE; z++) A.summary[SHK_SUM_STRIDE * r + z] = 0; }
-    }
-    return;
+  const uint32_t nruns_old = orrank[SHK_IMG_BLOCKS];
+  if (nruns_old != oorank[SHK_REGION_BLOCKS] || nruns_old > SHK_REGION) {
+    if (tid == 0) atomicOr(A.err, SHK_E_CORRUPT);
+    fatal = true;
   }
+  // position of the j-th runend: one lane per run (select over the masked runends words)
+  if (!fatal)
+    for (uint32_t j = tid; j < nruns_old; j += nthr) {
+      uint32_t lo = 0, hi = SHK_IMG_BLOCKS;   // last word w with orrank[w] <= j
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (orrank[mid] <= j) lo = mid; else hi = mid;
+      }
+      orend[j] = (uint16_t)(lo * 64 + shk_select64(orunw[lo], j - orrank[lo]));
+    }
 
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
-  if (!(A.ablate & 16))
   for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
     if (hkey[h] != SHK_EMPTY) atomicAdd(&qcnt[hkey[h] >> (SHK_CHUNK_BITS + 8)], 1u);
   __syncthreads();
-  const uint32_t per = SHK_REGION / nthr;  // consecutive quotients per thread (nthr divides 2048)
+  constexpr uint32_t per = SHK_REGION / nthr;  // consecutive quotients per lane
   const uint32_t qa = tid * per;
   {
-    uint32_t s = 0;
-    for (uint32_t j = 0; j < per; j++) s += qcnt[qa + j];
-    uint32_t tot;
-    uint32_t ex = shk_block_exscan(s, &tot, scratch32);
+    uint32_t sacc = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < per; j++) sacc += qcnt[qa + j];
+    uint32_t ex = shk_wave_incl_add(sacc) - sacc;
+#pragma unroll
     for (uint32_t j = 0; j < per; j++) { qoff[qa + j] = (uint16_t)ex; ex += qcnt[qa + j]; }
     if (tid == nthr - 1) qoff[SHK_REGION] = (uint16_t)ex;
   }
   __syncthreads();
-  if (!(A.ablate & 16))
   for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
     if (hkey[h] != SHK_EMPTY) {
-      uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
-      uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
+      const uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
+      const uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
       nidx[pos] = (uint16_t)h;
     }
   __syncthreads();
@@ -262,22 +288,26 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     const uint32_t q = qa + j;
     const uint32_t a = qoff[q], b = qoff[q + 1];
     for (uint32_t i = a + 1; i < b; i++) {  // insertion sort: runs are short
-      uint16_t x = nidx[i];
-      uint32_t rx = (hkey[x] >> SHK_CHUNK_BITS) & 0xff;
+      const uint16_t x = nidx[i];
+      const uint32_t rx = (hkey[x] >> SHK_CHUNK_BITS) & 0xff;
       uint32_t k2 = i;
       while (k2 > a && ((hkey[nidx[k2 - 1]] >> SHK_CHUNK_BITS) & 0xff) > rx) { nidx[k2] = nidx[k2 - 1]; k2--; }
       nidx[k2] = x;
     }
   }
-  // (each thread sorted only its own quotients' segments: no barrier needed before it reads them)
+  // (each lane sorted only its own quotients' segments)
 
-  // ---- pass over the quotients: merged run lengths (and statistics in the summary launch)
-  uint64_t my_new = 0, my_removed = 0, my_before = 0;
+  // ---- one pass over the quotients: merge old run and new keys -> run length, statistics,
+  // and (write modes) the run's encoding staged per lane
+  uint32_t my_new = 0, my_removed = 0, my_before = 0;
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  uint32_t st_used = 0;            // staged bytes of this lane
+  bool st_over = false;            // a run did not fit: this lane re-merges at placement time
+  uint8_t *mystage = stage + tid * SHK_STAGE_PER_LANE;
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
     uint32_t len = 0;
-    if (q < nq && !(A.ablate & 2)) {
+    if (q < nq && !fatal && !(A.ablate & 2)) {
       const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
       uint32_t opos = 0, oend = 0;
       bool ohas = false;
@@ -291,8 +321,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
       uint32_t ni = qoff[q];
       const uint32_t ne = qoff[q + 1];
       uint32_t orem = 0, on = 0; uint64_t ocnt = 0;
-      if (ohas) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt);
-      // head of the new list is kept in registers and reloaded only when it advances
+      if (ohas) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
       uint32_t nrem = 256, nh = 0, nkey = 0;
       if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
       while (ohas || ni < ne) {
@@ -307,7 +336,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
           }
           if (orem == nrem) { total += hcnt[nh]; adv = true; }
           opos += on;
-          if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
+          if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt); else ohas = false;
         } else {
           rem = nrem; total = hcnt[nh]; is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); adv = true;
         }
@@ -317,16 +346,36 @@ __global__ void k_region_merge(ShkMergeArgs A) {
           if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
         }
         if (A.denoise && total < 2 && !prot) { my_removed++; continue; }
-        if (!WRITE && is_new) {
+        if (is_new) {
           my_new++;
-          if (!A.want_hist) {
-          } else if (mc < A.hist_base) my_before++;
-          else {
-            uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
-            if (!(A.ablate & 32)) atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
+          if (MODE != 1 && A.want_hist) {
+            if (mc < A.hist_base) my_before++;
+            else {
+              uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
+              atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
+            }
           }
         }
-        len += shk_enc_len(rem, total);
+        const unsigned el = shk_enc_len_fast(rem, total);
+        if (WRITE) {
+          if (!st_over && st_used + el <= SHK_STAGE_PER_LANE) {
+            if (total <= 128) {           // fast encode
+              mystage[st_used] = (uint8_t)rem;
+              if (total > 1) {
+                const unsigned cdig = (unsigned)(total - 1);
+                unsigned o = 1;
+                if (cdig > rem) mystage[st_used + o++] = 0;
+                mystage[st_used + o] = (uint8_t)cdig;
+              }
+            } else {
+              uint8_t enc[12];
+              const unsigned n = shk_enc_write(enc, rem, total);
+              for (unsigned i = 0; i < n; i++) mystage[st_used + i] = enc[i];
+            }
+            st_used += el;
+          } else st_over = true;
+        }
+        len += el;
       }
       if (len) {
         ShkMP m; m.a = len; m.b = (long long)q + len;
@@ -335,41 +384,127 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     }
     qcnt[q] = len;
   }
-  ShkMP tot;
-  ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
+  // wave scan of the free-pointer functions (lane order = quotient order)
+  ShkMP incl = mine;
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    ShkMP y;
+    y.a = __shfl_up(incl.a, d);
+    y.b = __shfl_up(incl.b, d);
+    if (tid >= (unsigned)d) incl = shk_mp_compose(y, incl);
+  }
+  ShkMP tot, pre;
+  tot.a = __shfl(incl.a, SHK_WAVE - 1);
+  tot.b = __shfl(incl.b, SHK_WAVE - 1);
+  pre.a = __shfl_up(incl.a, 1);
+  pre.b = __shfl_up(incl.b, 1);
+  if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
 
-  if (!WRITE) {
-    // per-region counts are < 2^32 (a batch holds < 2^32 keys): two packed sums
-    const uint64_t s1 = shk_block_sum64((my_added << 32) | my_new, scratch64);
-    const uint64_t s2 = shk_block_sum64((my_removed << 32) | my_before, scratch64);
-    const uint64_t t_added = s1 >> 32, t_new = s1 & 0xffffffffu, t_removed = s2 >> 32, t_before = s2 & 0xffffffffu;
-    if (tid == 0) {
-      // per-region statistics go to memory; k_region_scan_c adds them up (one atomic per
-      // tile instead of millions on the same four words)
+  // per-region statistics (summed later by k_region_scan_c / k_stats_reduce: no same-address atomics)
+  if (MODE != 1) {
+    const uint32_t t_added = shk_wave_incl_add(my_added), t_new = shk_wave_incl_add(my_new),
+                   t_removed = shk_wave_incl_add(my_removed), t_before = shk_wave_incl_add(my_before);
+    if (tid == SHK_WAVE - 1) {
       uint32_t *sm = A.summary + (size_t)SHK_SUM_STRIDE * r;
-      sm[0] = (uint32_t)tot.a;
-      sm[1] = tot.b > 0 ? (uint32_t)tot.b : 0;
-      sm[2] = (uint32_t)t_new; sm[3] = (uint32_t)t_added; sm[4] = (uint32_t)t_removed; sm[5] = (uint32_t)t_before;
+      sm[0] = fatal ? 0 : (uint32_t)tot.a;
+      sm[1] = (!fatal && tot.b > 0) ? (uint32_t)tot.b : 0;
+      sm[2] = t_new; sm[3] = t_added; sm[4] = t_removed; sm[5] = t_before;
       if (tot.a > 0xFFFF) atomicOr(A.err, SHK_E_RUN_TOO_LONG);
       if (s_fail) atomicOr(A.err, s_fail);
     }
-    if (tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
-    return;
+    if (A.want_hist && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
   }
+  if (MODE == 0) return;
 
-  // ================= write pass =================
-  const long long fin_rel = (long long)A.finB[r] - (long long)q0;
-  const long long fout_rel = (long long)A.finB[r + 1] - (long long)q0;
+  // ================= placement =================
+  long long fin_rel, fout_rel;
+  if (MODE == 1) {
+    fin_rel = (long long)A.finB[r] - (long long)q0;
+    fout_rel = (long long)A.finB[r + 1] - (long long)q0;
+  } else {
+    // ---- single launch: look back over the regions before this one.
+    // Every region publishes (T, c) as soon as it knows them (lb_agg) and its outgoing free
+    // pointer once it knows its own incoming one (lb_incl). A window r'..r-1 composes to
+    // f -> max(f + a, b); since no region's runs may end more than SHK_IMG_SLOTS behind its
+    // start, f_in(r') <= start(r') + SHK_IMG_SLOTS - SHK_REGION, so the window already decides
+    // f_in(r) = b as soon as start(r') + SHK_IMG_SLOTS - SHK_REGION + a <= b.
+    if (tid == 0) {
+      const uint32_t c_rel = (!fatal && tot.b > 0) ? (uint32_t)tot.b : 0;
+      __hip_atomic_store(&A.lb_agg[r], (unsigned long long)(SHK_LB_VALID | ((uint32_t)tot.a << 12)) << 32 | c_rel,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    long long f_in = 0;
+    bool done = (r == 0);
+    ShkMP win; win.a = 0; win.b = SHK_NEG_INF;       // composition of the regions already walked (nearest first)
+    uint32_t back = 0;                                // regions walked so far
+    uint32_t spins = 0;
+    while (!done) {
+      const long long rr = (long long)r - 1 - back - tid;   // this lane's predecessor
+      unsigned long long incl_w = 0, agg_w = 0;
+      if (rr >= 0) {
+        incl_w = __hip_atomic_load(&A.lb_incl[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(incl_w & SHK_LB_INCL)) agg_w = __hip_atomic_load(&A.lb_agg[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const bool has_incl = rr >= 0 && (incl_w & SHK_LB_INCL);
+      const bool has_agg = rr >= 0 && ((agg_w >> 32) & SHK_LB_VALID);
+      const bool ready = rr < 0 || has_incl || has_agg;
+      // lanes are ordered nearest-first; use the prefix of lanes that are ready
+      const unsigned long long ready_m = __ballot(ready);
+      const unsigned nready = ready_m == ~0ULL ? 64u : (unsigned)(__ffsll((long long)~ready_m) - 1);
+      const unsigned long long stop_m = __ballot(rr < 0 || has_incl);   // lanes that end the walk
+      // compose lane by lane (wave-uniform loop over the ready prefix)
+      unsigned used = 0;
+      for (; used < nready; used++) {
+        const long long rr_u = (long long)r - 1 - back - used;
+        if ((stop_m >> used) & 1) {
+          const unsigned long long iw = __shfl(incl_w, used);
+          const long long fo = rr_u < 0 ? 0 : (long long)(iw & ~SHK_LB_INCL);
+          f_in = shk_mp_apply(win, fo);
+          done = true;
+          break;
+        }
+        const unsigned long long aw = __shfl(agg_w, used);
+        ShkMP m;
+        m.a = (long long)(((aw >> 32) & 0x7FFFFFFFu) >> 12);
+        const uint32_t c_rel = (uint32_t)aw;
+        m.b = c_rel ? rr_u * SHK_REGION + c_rel : SHK_NEG_INF;
+        win = shk_mp_compose(m, win);      // farther region first, then what we had
+        const long long bound = rr_u * SHK_REGION + (SHK_IMG_SLOTS - SHK_REGION);
+        if (bound + win.a <= win.b) { f_in = win.b; done = true; break; }
+      }
+      if (!done) {
+        back += used;
+        if (used == 0) {
+          if (++spins > (1u << 18)) { if (tid == 0) atomicOr(A.err, SHK_E_LOOKBACK); fatal = true; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+    }
+    // tot is in region-relative slots; f_in is absolute
+    const long long f_out = fatal ? 0 : shk_mp_apply(tot, f_in - (long long)q0) + (long long)q0;
+    if (tid == 0 && !(fatal && spins > (1u << 18)))
+      __hip_atomic_store(&A.lb_incl[r], SHK_LB_INCL | (unsigned long long)f_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      A.finB[r + 1] = (uint64_t)f_out;
+      if (r == 0) A.finB[0] = 0;
+      if (tot.a > 0 && f_out - (long long)q0 > SHK_IMG_SLOTS) atomicOr(A.err, SHK_E_NEW_EXTENT);
+      if ((uint64_t)f_out > A.xnslots) atomicOr(A.err, SHK_E_TABLE_FULL);
+    }
+    fin_rel = f_in - (long long)q0;
+    fout_rel = f_out - (long long)q0;
+  }
+  if (fatal) return;
   const uint32_t out_lo = fin_rel > 0 ? (uint32_t)fin_rel : 0;
   const bool new_any = tot.a > 0;
   const uint32_t out_hi = new_any ? (uint32_t)fout_rel : out_lo;
-  if (new_any && (fout_rel > SHK_IMG_SLOTS || fout_rel < 0)) {  // the scan kernel flags this too
+  if (new_any && (fout_rel > SHK_IMG_SLOTS || fout_rel < 0)) {
     if (tid == 0) atomicOr(A.err, SHK_E_NEW_EXTENT);
     return;
   }
+  // run starts and block offsets: walk my quotients with the running free pointer; place the staged bytes
+  uint32_t *nimg32 = reinterpret_cast<uint32_t *>(nimg);
   {
-    // run starts and block offsets: walk my quotients with the running free pointer
     long long f = shk_mp_apply(pre, fin_rel);
+    uint32_t so = 0;
     for (uint32_t j = 0; j < per; j++) {
       const uint32_t q = qa + j;
       if (q < nq && (q & 63) == 0) {
@@ -380,15 +515,24 @@ __global__ void k_region_merge(ShkMergeArgs A) {
       }
       const uint32_t len = qcnt[q];
       if (len) {
-        long long st = f > (long long)q ? f : (long long)q;
-        rstart[q] = (uint16_t)st;
-        f = st + len;
+        const long long stt = f > (long long)q ? f : (long long)q;
+        rstart[q] = (uint16_t)stt;
+        f = stt + len;
+        if (!st_over) {
+          const uint32_t wp = (uint32_t)stt;
+          for (uint32_t i = 0; i < len; i++) nimg[shk_img_slot_off(wp + i)] = mystage[so + i];
+          so += len;
+          const uint32_t last = wp + len - 1;  // runend bit on the run's last slot; occupied bit on q
+          const uint32_t bo = (last >> 6) * SHK_BLOCK_BYTES + SHK_OFF_RUN + ((last & 63) >> 3);
+          atomicOr(&nimg32[bo >> 2], 1u << (((bo & 3) << 3) + (last & 7)));
+          const uint32_t oo = (q >> 6) * SHK_BLOCK_BYTES + SHK_OFF_OCC + ((q & 63) >> 3);
+          atomicOr(&nimg32[oo >> 2], 1u << (((oo & 3) << 3) + (q & 7)));
+        }
       }
     }
   }
-  __syncthreads();
-  // encode the merged runs into the new image
-  uint32_t *nimg32 = reinterpret_cast<uint32_t *>(nimg);
+  // lanes whose runs did not fit the staging area merge once more, writing straight into the image
+  if (st_over)
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
     if (q >= nq || qcnt[q] == 0 || (A.ablate & 4)) continue;
@@ -434,7 +578,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
       for (unsigned i = 0; i < n; i++) nimg[shk_img_slot_off(wp + i)] = enc[i];
       wp += n;
     }
-    const uint32_t last = wp - 1;  // runend bit on the run's last slot; occupied bit on q
+    const uint32_t last = wp - 1;
     {
       const uint32_t bo = (last >> 6) * SHK_BLOCK_BYTES + SHK_OFF_RUN + ((last & 63) >> 3);
       atomicOr(&nimg32[bo >> 2], 1u << (((bo & 3) << 3) + (last & 7)));
@@ -445,9 +589,9 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   __syncthreads();
 
   // blocks past the last quotient hold only spilled runs: their offset bytes come from the
-  // final free pointer and are written by the last region's workgroup
+  // final free pointer and are written by the last region's wave
   if (r == gridDim.x - 1) {
-    const long long fend = (long long)A.finB[r + 1];
+    const long long fend = fout_rel + (long long)q0;
     for (uint64_t b = A.nslots / 64 + tid; b < A.nblocks; b += nthr) {
       long long o = fend - (long long)(64 * b);
       A.tabB[b * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
@@ -482,7 +626,7 @@ __global__ void k_region_merge(ShkMergeArgs A) {
     for (uint32_t m = m0 + tid; m <= m1; m += nthr) {
       const uint32_t bo = (m >> 3) * SHK_BLOCK_BYTES + SHK_OFF_RUN + (m & 7);
       const uint8_t v = nimg[bo];
-      if (vblk < nown && (m >> 3) >= vblk && (m >> 3) < nown) continue;  // written by the vector stores
+      if (vblk < nown && (m >> 3) >= vblk && (m >> 3) < nown) continue;  // written by the dword stores
       if (m == m0 || m == m1) {
         if (v) {
           uint8_t *addr = tb + bo;
@@ -497,9 +641,22 @@ __global__ void k_region_merge(ShkMergeArgs A) {
   }
 }
 
+// statistics of a single-launch rebuild (MODE 2): sum the per-region records
+__global__ void k_stats_reduce(const uint32_t *summary, uint32_t nregions, unsigned long long *counters) {
+  __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
+  const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
+  const uint32_t r0 = blockIdx.x * SHK_RSCAN_TILE + threadIdx.x * per;
+  for (int z = 0; z < 4; z++) {
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < per; j++)
+      if (r0 + j < nregions) v += summary[(size_t)SHK_SUM_STRIDE * (r0 + j) + 2 + z];
+    const uint64_t t = shk_block_sum64(v, scratch64);
+    if (threadIdx.x == 0 && t) atomicAdd(&counters[z], (unsigned long long)t);
+  }
+}
+
 // ---------------------------------------------------------------- free pointers
 // fin[r+1] = max(fin[r] + T_r, region start + c_r), as a 3-launch scan over tiles of regions.
-#define SHK_RSCAN_TILE 4096
 __device__ __forceinline__ ShkMP shk_region_mp(const uint32_t *summary, uint32_t r, uint32_t nregions) {
   ShkMP m; m.a = 0; m.b = SHK_NEG_INF;
   if (r < nregions) {

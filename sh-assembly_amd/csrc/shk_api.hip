@@ -19,11 +19,11 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
-  "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>",
+  "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
   "k_denoise_marks", "k_lookup", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
@@ -60,6 +60,8 @@ struct shk_ctx {
   uint32_t *d_tfb;
   uint32_t *d_summary;
   long long *d_tile_a, *d_tile_b, *d_tile_f;
+  unsigned long long *d_lb_agg, *d_lb_incl;
+  int single_ok;                // 0 after the single-launch rebuild had to give up once (then the two-launch scheme is used)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -105,7 +107,7 @@ static void prof_collect(shk_ctx *c) {
 static int map_err_bits(uint32_t bits) {
   if (!bits) return SHK_OK;
   if (bits & SHK_E_TABLE_FULL) return SHK_ERR_TABLE_FULL;
-  if (bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT | SHK_E_HASH_FULL | SHK_E_RUN_TOO_LONG)) return SHK_ERR_REGION;
+  if (bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT | SHK_E_HASH_FULL | SHK_E_RUN_TOO_LONG | SHK_E_LOOKBACK)) return SHK_ERR_REGION;
   if (bits & SHK_E_CORRUPT) return SHK_ERR_CORRUPT;
   if (bits & SHK_E_BAD_FASTQ) return SHK_ERR_FASTQ;
   if (bits & SHK_E_KEYS_FULL) return SHK_ERR_BATCH;
@@ -208,6 +210,8 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   }
   if (dmalloc(&c->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_summary, SHK_SUM_STRIDE * (uint64_t)c->nregions + 8)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_lb_agg, (uint64_t)c->nregions + 2) || dmalloc(&c->d_lb_incl, (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
+  c->single_ok = getenv("SHK_TWO_LAUNCH") ? 0 : 1;
   { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
     if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
   if (dmalloc(&c->d_counters, 4 + SHK_HIST_BINS)) return SHK_ERR_HIP;
@@ -235,7 +239,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
-  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
+  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
   hipHostFree(c->h_pinned);
   hipStreamDestroy(c->stream);
   delete c;
@@ -259,7 +263,7 @@ static int fetch_err(shk_ctx *c, uint32_t *bits) {
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   *bits = *(uint32_t *)(c->h_pinned + 40);
-  c->last_err_bits = *bits;
+  if (*bits) c->last_err_bits = *bits;
   if (*bits) hipMemsetAsync(c->d_err, 0, 16, c->stream);
   return 0;
 }
@@ -353,6 +357,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
+  A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -363,7 +368,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SUM);
-    hipLaunchKernelGGL((k_region_merge<false>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<0>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
     hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
@@ -377,7 +382,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   o->newd = c->h_pinned[0]; o->added = c->h_pinned[1]; o->removed = c->h_pinned[2]; o->before = c->h_pinned[3];
   for (int i = 0; i < SHK_HIST_BINS; i++) o->hist[i] = c->h_pinned[4 + i];
   o->err = *(uint32_t *)(c->h_pinned + 40);
-  c->last_err_bits = o->err;
+  if (o->err) c->last_err_bits = o->err;
   if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
   return SHK_OK;
 }
@@ -388,11 +393,40 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   fill_args(c, &A, words, lo, hi, 0, 0, denoise);
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_WRITE);
-    hipLaunchKernelGGL((k_region_merge<true>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<1>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   return SHK_OK;
 }
+
+// Single-launch rebuild: statistics and table B in one pass (free pointers by look-back).
+// The live table is NOT flipped here; the caller commits with commit_single() once it has
+// looked at the statistics (a deNoise point inside the range means the pass is discarded).
+static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int denoise, MergeOut *o) {
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, 0, 0, denoise, 0);
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_lb_agg, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
+  { ProfScope ps(c, KP_MERGE_SINGLE);
+    hipLaunchKernelGGL((k_region_merge<2>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+  { ProfScope ps(c, KP_REGION_SCAN);
+    const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
+    hipLaunchKernelGGL(k_stats_reduce, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_counters); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  o->newd = c->h_pinned[0]; o->added = c->h_pinned[1]; o->removed = c->h_pinned[2]; o->before = c->h_pinned[3];
+  for (int i = 0; i < SHK_HIST_BINS; i++) o->hist[i] = 0;
+  o->err = *(uint32_t *)(c->h_pinned + 40);
+  if (o->err) c->last_err_bits = o->err;
+  if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  if (o->err & SHK_E_LOOKBACK) c->single_ok = 0;
+  return SHK_OK;
+}
+static void commit_single(shk_ctx *c) { c->cur ^= 1; }
 
 static int denoise_round(shk_ctx *c, uint64_t *removed) {
   uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
@@ -400,11 +434,21 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
     hipLaunchKernelGGL(k_denoise_marks, dim3(1), dim3(64), 0, c->stream, c->tab[c->cur], c->nslots, c->xnslots, c->nblocks,
                        ml, (unsigned long long *)(c->d_scalars + 3)); }
   MergeOut o;
-  int rc = merge_summary(c, nullptr, 0, 0, 0, 0, 1, &o);
-  if (rc) return rc;
-  if (o.err) return map_err_bits(o.err);
-  rc = merge_write(c, nullptr, 0, 0, 1);
-  if (rc) return rc;
+  int rc;
+  bool done = false;
+  if (c->single_ok) {
+    rc = merge_single(c, nullptr, 0, 0, 1, &o);
+    if (rc) return rc;
+    if (!o.err) { commit_single(c); done = true; }
+    else if (!(o.err & SHK_E_LOOKBACK)) return map_err_bits(o.err);
+  }
+  if (!done) {
+    rc = merge_summary(c, nullptr, 0, 0, 0, 0, 1, &o);
+    if (rc) return rc;
+    if (o.err) return map_err_bits(o.err);
+    rc = merge_write(c, nullptr, 0, 0, 1);
+    if (rc) return rc;
+  }
   c->nelts -= o.removed;        // CQF_mt.h:1037-1038
   c->ndistinct -= o.removed;
   *removed = o.removed;
@@ -425,6 +469,22 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
     MergeOut o;
     uint32_t shift;
     int rc;
+    if (c->single_ok) {
+      // common case: no deNoise point inside [lo, hi] -> one launch does statistics and table
+      rc = merge_single(c, words, lo, hi, 0, &o);
+      if (rc) return rc;
+      if (o.err & ~(soft | SHK_E_HASH_FULL | SHK_E_LOOKBACK)) return map_err_bits(o.err & ~(soft | SHK_E_HASH_FULL | SHK_E_LOOKBACK));
+      const bool crosses = watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise;
+      if (!o.err && !crosses) {
+        commit_single(c);
+        c->ndistinct += o.newd; c->nelts += o.added;
+        st->kmers += o.added; st->new_distinct += o.newd; st->chunks += hi - lo + 1;
+        lo = hi + 1;
+        continue;
+      }
+      if (!crosses && (o.err & soft) && !(o.err & (SHK_E_HASH_FULL | SHK_E_LOOKBACK))) return map_err_bits(o.err);
+      // otherwise (deNoise point inside, hash overflow, or look-back gave up): the two-launch path below
+    }
     for (;;) {
       uint32_t span = hi - lo + 1;
       shift = 0;

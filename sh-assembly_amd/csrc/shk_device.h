@@ -36,6 +36,7 @@
 #define SHK_E_BAD_FASTQ    (1u << 5)   // read longer than 65535 / k out of range
 #define SHK_E_KEYS_FULL    (1u << 6)   // batch produced more keys than the key buffer holds
 #define SHK_E_RUN_TOO_LONG (1u << 7)
+#define SHK_E_LOOKBACK     (1u << 8)   // single-launch rebuild gave up waiting for a predecessor (host falls back)
 
 __device__ __forceinline__ unsigned shk_lane() { return threadIdx.x & (SHK_WAVE - 1); }
 __device__ __forceinline__ unsigned shk_wave() { return threadIdx.x / SHK_WAVE; }

@@ -12,6 +12,7 @@
 // (one workgroup is alive at a time).
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -54,6 +55,10 @@ static inline EmuWave *emu_wave() { return &emu_block->waves[threadIdx.x / 64]; 
 static inline void emu_wave_barrier() { pthread_barrier_wait(&emu_wave()->bar); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_sleep(n) sched_yield()
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 template <typename T> static inline T emu_xchg(T v, int src_lane, bool valid) {
