@@ -402,9 +402,10 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
 // Single-launch rebuild: statistics and table B in one pass (free pointers by look-back).
 // The live table is NOT flipped here; the caller commits with commit_single() once it has
 // looked at the statistics (a deNoise point inside the range means the pass is discarded).
-static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int denoise, MergeOut *o) {
+static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int denoise, MergeOut *o,
+                        int want_hist = 0, uint32_t hbase = 0, uint32_t hshift = 0) {
   ShkMergeArgs A;
-  fill_args(c, &A, words, lo, hi, 0, 0, denoise, 0);
+  fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->d_lb_agg, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
@@ -419,7 +420,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   o->newd = c->h_pinned[0]; o->added = c->h_pinned[1]; o->removed = c->h_pinned[2]; o->before = c->h_pinned[3];
-  for (int i = 0; i < SHK_HIST_BINS; i++) o->hist[i] = 0;
+  for (int i = 0; i < SHK_HIST_BINS; i++) o->hist[i] = c->h_pinned[4 + i];
   o->err = *(uint32_t *)(c->h_pinned + 40);
   if (o->err) c->last_err_bits = o->err;
   if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
@@ -458,7 +459,7 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
 // Insert the words of chunks [0, nchunks) (already partitioned in `words`), firing deNoise
 // rounds where the t = 1 reference would: after the first chunk at which
 // ndistinct >= trigger while rounds are left (CQF_mt.h:837, 860-869).
-static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_batch_stats *st) {
+static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint64_t nwords, shk_batch_stats *st) {
   // A summary over chunks that will turn out to lie behind a deNoise point is speculative:
   // "table full"/"extent" raised by its free-pointer scan mean nothing then.
   const uint32_t soft = SHK_E_TABLE_FULL | SHK_E_NEW_EXTENT;
@@ -469,9 +470,19 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
     MergeOut o;
     uint32_t shift;
     int rc;
+    bool have_hist = false;
+    {
+      uint32_t span = hi - lo + 1;
+      shift = 0;
+      while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
+    }
     if (c->single_ok) {
-      // common case: no deNoise point inside [lo, hi] -> one launch does statistics and table
-      rc = merge_single(c, words, lo, hi, 0, &o);
+      // common case: no deNoise point inside [lo, hi] -> one launch does statistics and table.
+      // When the trigger is within reach of this batch the same launch also fills the
+      // first-chunk histogram, so a discarded pass still yields the coarse position.
+      const bool possible = watch && c->ndistinct + nwords >= c->cfg.ndistinct_for_denoise;
+      rc = merge_single(c, words, lo, hi, 0, &o, possible ? 1 : 0, lo, shift);
+      have_hist = possible && !(o.err & ~soft);
       if (rc) return rc;
       if (o.err & ~(soft | SHK_E_HASH_FULL | SHK_E_LOOKBACK)) return map_err_bits(o.err & ~(soft | SHK_E_HASH_FULL | SHK_E_LOOKBACK));
       const bool crosses = watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise;
@@ -486,6 +497,7 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
       // otherwise (deNoise point inside, hash overflow, or look-back gave up): the two-launch path below
     }
     for (;;) {
+      if (have_hist) break;   // statistics of [lo, hi] are already known from the discarded single launch
       uint32_t span = hi - lo + 1;
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
@@ -505,9 +517,11 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
       // locate the first chunk at which the running distinct count reaches the trigger:
       // only now is the per-chunk histogram of first occurrences needed
       uint32_t base = lo;
-      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, 1);
-      if (rc) return rc;
-      if (o.err & ~soft) return map_err_bits(o.err & ~soft);
+      if (!have_hist) {
+        rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, 1);
+        if (rc) return rc;
+        if (o.err & ~soft) return map_err_bits(o.err & ~soft);
+      }
       for (;;) {
         uint32_t bin = 0;
         uint64_t run = c->ndistinct + o.before;
@@ -530,13 +544,29 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, shk_
         if (o.err & ~soft) return map_err_bits(o.err & ~soft);
       }
       fire = true;
-      // summary for exactly the chunks [lo, hi]
-      rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o);
+      // rebuild for exactly the chunks [lo, hi]
+      bool written = false;
+      if (c->single_ok) {
+        rc = merge_single(c, words, lo, hi, 0, &o);
+        if (rc) return rc;
+        if (!o.err) { commit_single(c); written = true; }
+        else if (!(o.err & SHK_E_LOOKBACK)) return map_err_bits(o.err);
+      }
+      if (!written) {
+        rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o);
+        if (rc) return rc;
+        if (o.err) return map_err_bits(o.err);
+        rc = merge_write(c, words, lo, hi, 0);
+        if (rc) return rc;
+      }
+    } else {
+      if (o.err) return map_err_bits(o.err);
+      if (have_hist) {
+        // (only reached when the single launch was clean but is not committed: cannot happen without a crossing)
+      }
+      rc = merge_write(c, words, lo, hi, 0);
       if (rc) return rc;
     }
-    if (o.err) return map_err_bits(o.err);
-    rc = merge_write(c, words, lo, hi, 0);
-    if (rc) return rc;
     c->ndistinct += o.newd;
     c->nelts += o.added;
     st->kmers += o.added;
@@ -583,7 +613,7 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   int dst = 0;
   rc = partition_stage(c, 0, nwords, &dst);
   if (rc) return finish(c, rc);
-  rc = merge_stage(c, c->d_words[dst], nchunks, &st);
+  rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
   return finish(c, rc);
 }
@@ -616,7 +646,7 @@ extern "C" int shk_count_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwo
   int dst = 0;
   int rc = partition_stage(c, 0, nwords, &dst);
   if (rc) return finish(c, rc);
-  rc = merge_stage(c, c->d_words[dst], nchunks, &st);
+  rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
   return finish(c, rc);
 }
