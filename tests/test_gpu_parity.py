@@ -119,3 +119,70 @@ def test_lookup_and_traveled_marks():
     assert ctx.blocks() == q.blocks()
     ctx.close()
     q.free()
+
+
+def _upload(keys):
+    import torch
+    return torch.tensor(keys, dtype=torch.int64, device="cuda")
+
+
+def test_dense_clusters_and_saturated_offsets():
+    """shk_count_words on crafted keys: one clump of ~400 entries with large counts inside 64
+    quotients (block offsets saturate at 255, runs spill over many blocks), plus background.
+    Table bytes equal the canonical layout model and the oracle; lookups agree."""
+    import random
+    import torch
+    from cqf_canon import build_blocks
+    rnd = random.Random(7)
+    qb = 13
+    for trial in range(4):
+        tot = {}
+        base = rnd.randrange(0, 5000)
+        for _ in range(rnd.choice([250, 400])):
+            key = ((base + rnd.randrange(0, 64)) << 8) | rnd.randrange(256)
+            tot[key] = tot.get(key, 0) + rnd.choice([1, 1, 2, 3, 200, 20000])
+        for _ in range(1500):
+            key = (rnd.randrange(1 << qb) << 8) | rnd.randrange(256)
+            tot[key] = tot.get(key, 0) + rnd.choice([1, 1, 1, 2])
+        canon = build_blocks(qb, qb + 8, tot)
+        assert max(canon[b * 89] for b in range(len(canon) // 89)) == 255
+        # occurrences capped per key so the word list stays small; large counts via two batches of repeats
+        words = []
+        for key, c in tot.items():
+            words += [key] * min(c, 300)
+        small = {k: min(c, 300) for k, c in tot.items()}
+        rnd.shuffle(words)
+        ctx = _ctx(qb=qb, k=21, max_batch_bytes=64, max_batch_keys=len(words) + 16)
+        half = len(words) // 2
+        for part in (words[:half], words[half:]):
+            t = _upload(part)
+            torch.cuda.synchronize()
+            ctx.count_words(t.data_ptr(), t.numel(), 1)
+        assert ctx.blocks() == build_blocks(qb, qb + 8, small)
+        ks = list(small)[:500] + [rnd.randrange(1 << (qb + 8)) for _ in range(200)]
+        cnt, _ = ctx.lookup(ks, mode=2)
+        assert cnt == [small.get(k, 0) for k in ks]
+        ctx.close()
+
+
+def test_full_table_is_an_error_not_corruption():
+    """the reference overruns a full table; the library reports SHK_ERR_TABLE_FULL and leaves the table as it was"""
+    import random
+    import shk
+    import torch
+    rnd = random.Random(3)
+    qb = 10
+    ctx = _ctx(qb=qb, k=21, max_batch_bytes=64, max_batch_keys=1 << 14)
+    first = [(rnd.randrange(1 << qb) << 8) | rnd.randrange(256) for _ in range(300)]
+    t = _upload(first)
+    torch.cuda.synchronize()
+    ctx.count_words(t.data_ptr(), t.numel(), 1)
+    before = ctx.blocks()
+    many = [(rnd.randrange(1 << qb) << 8) | rnd.randrange(256) for _ in range(4000)]
+    t = _upload(many)
+    torch.cuda.synchronize()
+    with pytest.raises(shk.ShkError) as e:
+        ctx.count_words(t.data_ptr(), t.numel(), 1)
+    assert e.value.code in (-3, -4)
+    assert ctx.blocks() == before
+    ctx.close()
