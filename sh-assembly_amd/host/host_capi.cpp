@@ -7,6 +7,7 @@
 
 #include "fastq_chunker.hpp"
 #include "sizing.hpp"
+#include "stitch.hpp"
 
 extern "C" {
 // sizes of the parts getDataChunk hands out for a list of files (round robin), 0 = plain, 1 = gzip
@@ -18,6 +19,11 @@ uint64_t shkh_chunk_sizes(const char **paths, int nfiles, int mode, uint64_t par
   uint64_t n = 0;
   while (b.getDataChunk(c)) { if (n < cap) sizes[n] = c.get_size(); n++; free(c.get_reads()); }
   return n;
+}
+// shard tables -> the single table (see stitch.hpp)
+int shkh_stitch(const uint8_t *const *shards, const uint64_t *shard_blocks, uint32_t nshards, uint32_t qb, uint8_t *out,
+                uint64_t out_bytes) {
+  return shk::stitch_shards(shards, shard_blocks, nshards, qb, out, out_bytes);
 }
 void shkh_size_filter(int K, uint64_t n_true, uint64_t N_total, double alpha, int num_denoise, double fr, uint64_t *out) {
   shk::Sizing s = shk::size_filter(K, n_true, N_total, alpha, "", num_denoise, fr);

@@ -108,3 +108,41 @@ def test_import_then_count(shk, tmp_path):
     assert open(p2, "rb").read() == open(p3, "rb").read()
     ctx.close()
     q.free()
+
+
+def test_shards_stitch_to_single_table(shk):
+    """two quotient-range shards (own tables, own tails) stitched by host/stitch.cpp give the
+    bytes of the single filter, including a cluster that spills across the shard boundary"""
+    import random
+    from cqf_canon import build_blocks
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sh-assembly_amd"),
+                           os.path.join(ROOT, "sh-assembly_amd", "libshkhost.so")])
+    H = C.CDLL(os.path.join(ROOT, "sh-assembly_amd", "libshkhost.so"))
+    H.shkh_stitch.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64]
+    rnd = random.Random(11)
+    qb, G = 11, 2
+    half = (1 << qb) // G
+    tot = {}
+    for _ in range(700):
+        key = (rnd.randrange(1 << qb) << 8) | rnd.randrange(256)
+        tot[key] = tot.get(key, 0) + rnd.choice([1, 1, 2, 130])
+    for _ in range(90):   # a clump right below the boundary: its cluster spills into shard 1
+        key = ((half - 1 - rnd.randrange(20)) << 8) | rnd.randrange(256)
+        tot[key] = tot.get(key, 0) + rnd.choice([1, 2, 3])
+    shards = []
+    for g in range(G):
+        keys = [k for k, c in tot.items() if (k >> 8) // half == g for _ in range(min(c, 200))]
+        ctx = _ctx(shk, qb=qb, k=21, max_batch_bytes=64, max_batch_keys=len(keys) + 16, shard_index=g, num_shards=G)
+        arr = (C.c_uint64 * len(keys))(*keys)
+        ctx.count_words(C.addressof(arr), len(keys), 1)
+        shards.append(ctx.blocks())
+        ctx.close()
+    small = {k: min(c, 200) for k, c in tot.items()}
+    want = build_blocks(qb, qb + 8, small)
+    out = C.create_string_buffer(len(want))
+    ptrs = (C.c_char_p * G)(*shards)
+    nb = (C.c_uint64 * G)(*[len(s) // 89 for s in shards])
+    assert H.shkh_stitch(ptrs, nb, G, qb, out, len(want)) == 0
+    assert out.raw == want
+    # the spill really crossed the boundary in the single table
+    assert want[(half // 64) * 89] > 0
