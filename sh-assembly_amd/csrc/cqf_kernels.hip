@@ -42,6 +42,7 @@ struct ShkMergeArgs {
   uint32_t *err;
   unsigned long long *lb_agg;     // [nregions] look-back records of the single-launch rebuild (zeroed per launch)
   unsigned long long *lb_incl;    // [nregions]
+  unsigned long long *dbg;        // diagnostics only: per-phase cycle sums of sampled regions (null = off)
   uint32_t ablate;                // diagnostics only (SHK_ABLATE): skip phases to time them; results invalid
 };
 
@@ -127,8 +128,10 @@ __device__ __forceinline__ unsigned shk_img_dec_fast(const uint8_t *img, unsigne
 #define SHK_LB_VALID 0x80000000u
 #define SHK_LB_INCL (1ULL << 63)
 
+#define SHK_STAMP(i) do { if (A.dbg && (blockIdx.x & 63) == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&A.dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
+
 template <int MODE>
-__global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs A) {
+__global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A) {
   constexpr bool WRITE = MODE != 0;
   __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
   __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch
@@ -145,10 +148,12 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
   __shared__ uint32_t orrank[SHK_IMG_BLOCKS + 1];
   __shared__ uint32_t lhist[SHK_HIST_BINS];
-  __shared__ uint32_t s_fail;
+  __shared__ uint32_t s_fail, s_added;
 
+  unsigned long long t_prev = A.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned tid = threadIdx.x;
-  constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave
+  const unsigned ngrp = blockDim.x;              // all waves of the group: staging, init, key folding
+  constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave does the rest
   const uint32_t r = blockIdx.x;
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -163,7 +168,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
   const uint32_t ohi = old_any ? (uint32_t)((fa1 - q0) > 0xFFFFFFF ? 0xFFFFFFF : (fa1 - q0)) : olo;
   uint32_t nblk_old = old_any ? (ohi + 63) / 64 : 0;
   if (nblk_old < nown) nblk_old = nown;
-  if (tid == 0) s_fail = 0;
+  if (tid == 0) { s_fail = 0; s_added = 0; }
   bool fatal = false;
   if (nblk_old > SHK_IMG_BLOCKS || ohi > SHK_IMG_SLOTS) {
     if (tid == 0) atomicOr(A.err, SHK_E_OLD_EXTENT);
@@ -177,48 +182,69 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
     const uint32_t nbytes = nblk_old * SHK_BLOCK_BYTES;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
     uint32_t *dst = reinterpret_cast<uint32_t *>(oimg);
-    for (uint32_t i = tid; i < (nbytes + 3) / 4; i += nthr) dst[i] = src[i];
-    for (uint32_t i = tid; i < SHK_HCAP; i += nthr) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; }
-    for (uint32_t i = tid; i < SHK_REGION; i += nthr) qcnt[i] = 0;
+    if (!(A.ablate & 64)) for (uint32_t i = tid; i < (nbytes + 3) / 4; i += ngrp) dst[i] = src[i];
+    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; }
+    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) qcnt[i] = 0;
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
-      for (uint32_t i = tid; i < (SHK_IMG_BYTES + 16) / 4; i += nthr) z[i] = 0;
+      for (uint32_t i = tid; i < (SHK_IMG_BYTES + 16) / 4; i += ngrp) z[i] = 0;
     }
   }
   __syncthreads();
 
+  SHK_STAMP(0);   // staging + init
   // ---- fold this region's new keys into the LDS hash
   uint32_t my_added = 0;
-  if (A.words && !fatal) {
+  if (A.words && !fatal && !(A.ablate & 1)) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
     const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
-    for (uint64_t i = kb + tid; i < ke; i += nthr) {
-      const uint64_t w = A.words[i];
-      const uint32_t chunk = (uint32_t)(w >> A.hb);
-      if (chunk < A.chunk_lo || chunk > A.chunk_hi) continue;
-      const uint64_t key = w & kmask;
-      const uint32_t ql = (uint32_t)((key >> 8) - A.q_lo - q0);
-      if (ql >= nq) { atomicOr(A.err, SHK_E_CORRUPT); continue; }
-      const uint32_t tag = (ql << 8) | (uint32_t)(key & 0xff);
-      const uint32_t want = tag << SHK_CHUNK_BITS;
-      uint32_t h = (tag * 2654435761u) >> (32 - SHK_HCAP_LOG2);
-      bool placed = false;
-      for (uint32_t probe = 0; probe < SHK_HCAP; probe++) {
-        uint32_t cur = hkey[h];
-        if (cur == SHK_EMPTY) {
-          uint32_t prev = atomicCAS(&hkey[h], SHK_EMPTY, want | (SHK_MAX_CHUNKS - 1));
-          if (prev == SHK_EMPTY || (prev >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
-        } else if ((cur >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
-        h = (h + 1) & (SHK_HCAP - 1);
+    // four key words per lane are in flight before any of them is folded in: the loop is
+    // otherwise a chain of dependent HBM round trips
+    for (uint64_t i0 = kb; i0 < ke; i0 += 4 * ngrp) {
+      uint64_t wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t i = i0 + (uint64_t)u * ngrp + tid;
+        wv[u] = i < ke ? A.words[i] : ~0ULL;
       }
-      if (!placed) { atomicOr(&s_fail, SHK_E_HASH_FULL); continue; }
-      atomicMin(&hkey[h], want | chunk);
-      atomicAdd(&hcnt[h], 1u);
-      my_added++;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t w = wv[u];
+        if (i0 + (uint64_t)u * ngrp + tid >= ke) continue;
+        if (A.ablate & 256) { my_added += (uint32_t)(w & 1); continue; }   // diagnostics: loads only
+        const uint32_t chunk = (uint32_t)(w >> A.hb);
+        if (chunk < A.chunk_lo || chunk > A.chunk_hi) continue;
+        const uint64_t key = w & kmask;
+        const uint32_t ql = (uint32_t)((key >> 8) - A.q_lo - q0);
+        if (ql >= nq) { atomicOr(A.err, SHK_E_CORRUPT); continue; }
+        const uint32_t tag = (ql << 8) | (uint32_t)(key & 0xff);
+        const uint32_t want = tag << SHK_CHUNK_BITS;
+        uint32_t h = (tag * 2654435761u) >> (32 - SHK_HCAP_LOG2);
+        if (A.ablate & 2048) { my_added += h & 1; continue; }
+        if (A.ablate & 1024) { atomicAdd(&hcnt[h], 1u); my_added++; continue; }
+        bool placed = false;
+        for (uint32_t probe = 0; probe < SHK_HCAP; probe++) {
+          uint32_t cur = hkey[h];
+          if (cur == SHK_EMPTY) {
+            uint32_t prev = atomicCAS(&hkey[h], SHK_EMPTY, want | (SHK_MAX_CHUNKS - 1));
+            if (prev == SHK_EMPTY || (prev >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
+          } else if ((cur >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
+          h = (h + 1) & (SHK_HCAP - 1);
+        }
+        if (!placed) { atomicOr(&s_fail, SHK_E_HASH_FULL); continue; }
+        if (A.want_hist) atomicMin(&hkey[h], want | chunk);   // first chunk of the key: only the histogram needs it
+        if (!(A.ablate & 512)) atomicAdd(&hcnt[h], 1u);
+        my_added++;
+      }
     }
   }
+  if (my_added) atomicAdd(&s_added, my_added);
   __syncthreads();
+  // the helper waves are done: one wave carries on (its barriers below are wave-local)
+  if (tid >= nthr) return;
+  my_added = tid == 0 ? s_added : 0;
+  SHK_STAMP(1);   // key folding
 
   // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
   {
@@ -261,7 +287,9 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
       orend[j] = (uint16_t)(lo * 64 + shk_select64(orunw[lo], j - orrank[lo]));
     }
 
+  SHK_STAMP(2);   // old structure (rank/select)
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
+  if (!(A.ablate & 16))
   for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
     if (hkey[h] != SHK_EMPTY) atomicAdd(&qcnt[hkey[h] >> (SHK_CHUNK_BITS + 8)], 1u);
   __syncthreads();
@@ -297,6 +325,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
   }
   // (each lane sorted only its own quotients' segments)
 
+  SHK_STAMP(3);   // counting sort + per-quotient sort
   // ---- one pass over the quotients: merge old run and new keys -> run length, statistics,
   // and (write modes) the run's encoding staged per lane
   uint32_t my_new = 0, my_removed = 0, my_before = 0;
@@ -384,6 +413,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
     }
     qcnt[q] = len;
   }
+  SHK_STAMP(4);   // merge pass
   // wave scan of the free-pointer functions (lane order = quotient order)
   ShkMP incl = mine;
   for (int d = 1; d < SHK_WAVE; d <<= 1) {
@@ -413,7 +443,8 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
     }
     if (A.want_hist && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
   }
-  if (MODE == 0) return;
+  SHK_STAMP(5);   // scan + statistics
+  if (MODE == 0 || (A.ablate & 128)) return;
 
   // ================= placement =================
   long long fin_rel, fout_rel;
@@ -433,7 +464,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     long long f_in = 0;
-    bool done = (r == 0);
+    bool done = (r == 0) || (A.ablate & 32);
     ShkMP win; win.a = 0; win.b = SHK_NEG_INF;       // composition of the regions already walked (nearest first)
     uint32_t back = 0;                                // regions walked so far
     uint32_t spins = 0;
@@ -492,6 +523,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
     fin_rel = f_in - (long long)q0;
     fout_rel = f_out - (long long)q0;
   }
+  SHK_STAMP(6);   // look-back
   if (fatal) return;
   const uint32_t out_lo = fin_rel > 0 ? (uint32_t)fin_rel : 0;
   const bool new_any = tot.a > 0;
@@ -588,6 +620,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
   }
   __syncthreads();
 
+  SHK_STAMP(7);   // placement into the image
   // blocks past the last quotient hold only spilled runs: their offset bytes come from the
   // final free pointer and are written by the last region's wave
   if (r == gridDim.x - 1) {
@@ -639,6 +672,7 @@ __global__ void __launch_bounds__(SHK_MERGE_THREADS) k_region_merge(ShkMergeArgs
       }
     }
   }
+  SHK_STAMP(8);   // stores to table B
 }
 
 // statistics of a single-launch rebuild (MODE 2): sum the per-region records

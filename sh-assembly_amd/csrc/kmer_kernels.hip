@@ -201,6 +201,14 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
   const uint64_t mask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
   uint64_t *rg = ringG[wv], *rh_ = ringH[wv];
+  // Strips are 64 bases wide, so base j of a segment always sits in lane j & 63: every rotation
+  // amount of the closed form is a per-lane constant. Seeds are pre-rotated once per lane.
+  const uint64_t fA = shk_ror64(SHK_SEED_A, lane), fC = shk_ror64(SHK_SEED_C, lane), fG = shk_ror64(SHK_SEED_G, lane),
+                 fT = shk_ror64(SHK_SEED_T, lane);
+  const uint64_t rA = shk_rol64(SHK_SEED_T, lane), rC = shk_rol64(SHK_SEED_G, lane), rG = shk_rol64(SHK_SEED_C, lane),
+                 rT = shk_rol64(SHK_SEED_A, lane);   // complement seeds (nthash.hpp:15,299)
+  const unsigned rot_f = lane;                        // (k - 1 + p) & 63 with p = j + 1 - k
+  const unsigned rot_r = (lane + 1 + 64 * 4 - k) & 63;  // p & 63 (k <= 191 < 256)
   for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + wv; r < nreads; r += nwaves) {
     const uint64_t st = rd_start[r], en = rd_end[r];
     if (en - st > SHK_MAX_READ) continue;
@@ -230,14 +238,14 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
         const uint32_t j = t * 64 + lane;   // index in the segment
         uint64_t a = 0, c = 0;
         if (j < L) {
-          unsigned ch = rd[s + j];
-          a = shk_ror64(shk_seed_fwd(ch), j & 63);
-          c = shk_rol64(shk_seed_rc(ch), j & 63);
+          const unsigned ch = rd[s + j] & 0xDF;   // upper and lower case map alike (nthash.hpp:85-153); all else is 0
+          a = ch == 'A' ? fA : ch == 'C' ? fC : ch == 'G' ? fG : ch == 'T' ? fT : 0ULL;
+          c = ch == 'A' ? rA : ch == 'C' ? rC : ch == 'G' ? rG : ch == 'T' ? rT : 0ULL;
         }
         const uint64_t G1 = shk_wave_incl_xor64(a) ^ carryG;  // G(j+1)
         const uint64_t H1 = shk_wave_incl_xor64(c) ^ carryH;  // H(j+1)
-        carryG = __shfl(G1, SHK_WAVE - 1);
-        carryH = __shfl(H1, SHK_WAVE - 1);
+        carryG = shk_last_lane64(G1);
+        carryH = shk_last_lane64(H1);
         if (j < L) { rg[(j + 1) & 255] = G1; rh_[(j + 1) & 255] = H1; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -246,8 +254,8 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
         if (j < L && j + 1 >= k) {
           const uint32_t p = j + 1 - k;
           const uint64_t G0 = rg[p & 255], H0 = rh_[p & 255];
-          const uint64_t fh = shk_rol64(G1 ^ G0, (k - 1 + p) & 63);
-          const uint64_t rv = shk_ror64(H1 ^ H0, p & 63);
+          const uint64_t fh = shk_rol64(G1 ^ G0, rot_f);
+          const uint64_t rv = shk_ror64(H1 ^ H0, rot_r);
           const uint64_t hv = fh < rv ? fh : rv;
           words[out + p] = (hv & mask) | chunk_tag;
         }

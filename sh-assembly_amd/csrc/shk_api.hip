@@ -191,7 +191,8 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
       dmalloc(&c->d_reads_base, maxch + 1)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_rd_start, c->max_reads + 1) || dmalloc(&c->d_rd_end, c->max_reads + 1) ||
       dmalloc(&c->d_nkeys, c->max_reads + 1) || dmalloc(&c->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
-  if (dmalloc(&c->d_scalars, 8)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_scalars, 64)) return SHK_ERR_HIP;
+  HIPCHK(hipMemsetAsync(c->d_scalars, 0, 64 * 8, c->stream));
   {
     uint64_t mx = capk > c->max_reads ? capk : c->max_reads;
     uint64_t pw = 1ULL << c->rbits;
@@ -231,6 +232,13 @@ extern "C" void shk_destroy(shk_ctx *c) {
   if (!c) return;
   hipSetDevice(c->dev);
   hipStreamSynchronize(c->stream);
+  if (getenv("SHK_STAMPS")) {
+    unsigned long long st[16];
+    hipMemcpy(st, c->d_scalars + 16, sizeof(st), hipMemcpyDeviceToHost);
+    static const char *nm[9] = {"stage+init", "fold keys", "old rank/select", "count sort", "merge pass", "scan+stats", "look-back", "placement", "stores"};
+    unsigned long long tot = 0; for (int i = 0; i < 9; i++) tot += st[i];
+    for (int i = 0; i < 9; i++) fprintf(stderr, "SHK_STAMPS %-16s %6.2f %%\n", nm[i], tot ? 100.0 * st[i] / tot : 0.0);
+  }
   prof_collect(c);
   for (size_t i = 0; i < c->evpool.size(); i++) hipEventDestroy(c->evpool[i]);
   for (int i = 0; i < 2; i++) { hipFree(c->tab[i]); hipFree(c->fin[i]); hipFree(c->d_words[i]); }
@@ -358,6 +366,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
   A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
+  A->dbg = getenv("SHK_STAMPS") ? (unsigned long long *)(c->d_scalars + 16) : nullptr;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -368,7 +377,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SUM);
-    hipLaunchKernelGGL((k_region_merge<0>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<0>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
     hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
@@ -393,7 +402,7 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   fill_args(c, &A, words, lo, hi, 0, 0, denoise);
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_WRITE);
-    hipLaunchKernelGGL((k_region_merge<1>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<1>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   return SHK_OK;
@@ -411,7 +420,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_SINGLE);
-    hipLaunchKernelGGL((k_region_merge<2>), dim3(c->nregions), dim3(SHK_MERGE_THREADS), 0, c->stream, A); }
+    hipLaunchKernelGGL((k_region_merge<2>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
     hipLaunchKernelGGL(k_stats_reduce, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_counters); }

@@ -22,7 +22,8 @@
 #define SHK_IMG_BYTES (SHK_IMG_BLOCKS * SHK_BLOCK_BYTES)
 #define SHK_HCAP_LOG2 9
 #define SHK_HCAP (1u << SHK_HCAP_LOG2)                 // LDS hash capacity (distinct new keys per region)
-#define SHK_MERGE_THREADS 64                           // the rebuild kernels run one wave per region
+#define SHK_MERGE_THREADS 64                           // the rebuild kernels run one wave per region ...
+#define SHK_MERGE_GROUP 256                            // ... helped by three more waves while the batch keys are folded in
 #define SHK_CHUNK_BITS 12                              // chunk index field of a key word
 #define SHK_MAX_CHUNKS (1u << SHK_CHUNK_BITS)
 #define SHK_HIST_BINS 32
@@ -67,13 +68,27 @@ __device__ __forceinline__ uint64_t shk_wave_incl_add64(uint64_t x) {
   }
   return x;
 }
-__device__ __forceinline__ uint64_t shk_wave_incl_xor64(uint64_t x) {
-  unsigned lane = shk_lane();
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    uint64_t y = __shfl_up(x, d);
-    if (lane >= (unsigned)d) x ^= y;
-  }
+// Inclusive XOR scan over the 64 lanes with DPP moves (no LDS crossbar): Hillis-Steele inside
+// each row of 16 lanes (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 carry the row totals
+// across rows (GFX9 DPP modes, present on gfx950).
+__device__ __forceinline__ uint32_t shk_dpp_xor_scan32(uint32_t x) {
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+  x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
   return x;
+}
+__device__ __forceinline__ uint64_t shk_wave_incl_xor64(uint64_t x) {
+  const uint32_t lo = shk_dpp_xor_scan32((uint32_t)x), hi = shk_dpp_xor_scan32((uint32_t)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// value of lane 63, as a wave-uniform scalar
+__device__ __forceinline__ uint64_t shk_last_lane64(uint64_t x) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // ---- workgroup exclusive scan of one u32 per thread. `scratch` is SHK_MAX_WAVES+1 words of LDS.

@@ -7,12 +7,13 @@ thread_local EmuBlock *emu_block;
 void emu_launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   const unsigned nthr = block.x, nw = (nthr + 63) / 64;
   EmuBlock *eb = new EmuBlock();
-  pthread_barrier_init(&eb->bar, nullptr, nthr);
   for (unsigned w = 0; w < nw; w++) {
     unsigned cnt = std::min(64u, nthr - w * 64);
     pthread_barrier_init(&eb->waves[w].bar, nullptr, cnt);
   }
   for (unsigned b = 0; b < grid.x; b++) {
+    std::barrier<> bar(nthr);
+    eb->bar = &bar;
     std::vector<std::thread> ths;
     ths.reserve(nthr);
     for (unsigned t = 0; t < nthr; t++) {
@@ -20,11 +21,11 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         threadIdx = dim3(t); blockIdx = dim3(b); blockDim = block; gridDim = grid;
         emu_block = eb;
         body();
+        eb->bar->arrive_and_drop();
       });
     }
     for (auto &th : ths) th.join();
   }
   for (unsigned w = 0; w < nw; w++) pthread_barrier_destroy(&eb->waves[w].bar);
-  pthread_barrier_destroy(&eb->bar);
   delete eb;
 }

@@ -18,6 +18,7 @@
 #include <string.h>
 #include <time.h>
 #include <algorithm>
+#include <barrier>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -47,10 +48,11 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 enum { hipHostMallocDefault = 0 };
 
 struct EmuWave { pthread_barrier_t bar; uint64_t box[64]; };
-struct EmuBlock { pthread_barrier_t bar; EmuWave waves[16]; };
+// the workgroup barrier drops threads that have left the kernel (waves may exit early on the GPU too)
+struct EmuBlock { std::barrier<> *bar; EmuWave waves[16]; };
 extern thread_local EmuBlock *emu_block;
 
-static inline void __syncthreads() { pthread_barrier_wait(&emu_block->bar); }
+static inline void __syncthreads() { emu_block->bar->arrive_and_wait(); }
 static inline EmuWave *emu_wave() { return &emu_block->waves[threadIdx.x / 64]; }
 static inline void emu_wave_barrier() { pthread_barrier_wait(&emu_wave()->bar); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
@@ -59,6 +61,7 @@ static inline void emu_wave_barrier() { pthread_barrier_wait(&emu_wave()->bar); 
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_sleep(n) sched_yield()
+#define __builtin_amdgcn_s_memtime() 0ULL
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 template <typename T> static inline T emu_xchg(T v, int src_lane, bool valid) {
@@ -84,6 +87,21 @@ template <typename T> static inline T __shfl_down(T v, unsigned d) {
   return emu_xchg(v, l, l < 64);
 }
 template <typename T> static inline T __shfl_xor(T v, int m) { return emu_xchg(v, (int)(threadIdx.x & 63) ^ m, true); }
+// DPP move (the modes the kernels use: row_shr:n, row_shl:n, row_bcast15, row_bcast31)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = threadIdx.x & 63, row = lane >> 4, within = lane & 15;
+  int src_lane = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { int w = within - (ctrl - 0x110); if (w >= 0) src_lane = row * 16 + w; }
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) { int w = within + (ctrl - 0x100); if (w < 16) src_lane = row * 16 + w; }
+  else if (ctrl == 0x142) { if (row >= 1) src_lane = row * 16 - 1; }
+  else if (ctrl == 0x143) { if (row >= 2) src_lane = 31; }
+  const int got = emu_xchg(src, src_lane < 0 ? 0 : src_lane, true);
+  const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (within >> 2)) & 1);
+  if (!enabled) return old;
+  if (src_lane < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_xchg(v, lane, true); }
 static inline unsigned long long __ballot(int pred) {
   EmuWave *w = emu_wave();
   w->box[threadIdx.x & 63] = pred ? 1 : 0;
