@@ -73,7 +73,7 @@ def test_count_and_denoise_schedule(shk):
     assert ctx.blocks() == q.blocks()
     assert ctx.header() == oracle_header(q)
     # lookups + traveled marks against the oracle
-    keys = [kc[0] for kc in q.dump()[:40]] + [12345, 1 << 20, (1 << (qb + 8)) - 1]
+    keys = [kc[0] for kc in q.dump()[:40]] + [12345, 1 << (qb + 2), (1 << (qb + 8)) - 1]
     cnt, _ = ctx.lookup(keys, mode=2)
     assert cnt == [q.count(x) for x in keys]
     _, t1 = ctx.lookup(keys, mode=1)
