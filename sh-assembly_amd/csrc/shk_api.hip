@@ -73,6 +73,7 @@ struct shk_ctx {
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> evpool;
   uint32_t last_err_bits;
+  double new_frac;              // new distinct keys per presented k-mer in the last committed range (predicts crossings)
   int staged;                   // which d_words[] holds the partitioned words of shk_stage_words
 };
 
@@ -485,7 +486,12 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
     }
-    if (c->single_ok) {
+    // a deNoise point inside this range is likely when the last range's rate of new keys would
+    // carry the distinct count past the trigger: then the statistics-only launch runs first
+    const bool likely = watch && c->new_frac > 0 &&
+                        (double)c->ndistinct + 0.8 * c->new_frac * (double)nwords * (double)(hi - lo + 1) / (double)nchunks >=
+                            (double)c->cfg.ndistinct_for_denoise;
+    if (c->single_ok && !likely) {
       // common case: no deNoise point inside [lo, hi] -> one launch does statistics and table.
       // When the trigger is within reach of this batch the same launch also fills the
       // first-chunk histogram, so a discarded pass still yields the coarse position.
@@ -497,6 +503,7 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint
       const bool crosses = watch && c->ndistinct + o.newd >= c->cfg.ndistinct_for_denoise;
       if (!o.err && !crosses) {
         commit_single(c);
+        if (o.added) c->new_frac = (double)o.newd / (double)o.added;
         c->ndistinct += o.newd; c->nelts += o.added;
         st->kmers += o.added; st->new_distinct += o.newd; st->chunks += hi - lo + 1;
         lo = hi + 1;
@@ -510,8 +517,9 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint
       uint32_t span = hi - lo + 1;
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
-      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o);
+      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, likely ? 1 : 0);
       if (rc) return rc;
+      if (likely && !(o.err & ~soft)) have_hist = true;
       if (o.err & ~(soft | SHK_E_HASH_FULL)) return map_err_bits(o.err & ~(soft | SHK_E_HASH_FULL));
       if (o.err & SHK_E_HASH_FULL) {
         // more distinct new keys in one region than its LDS hash holds: take fewer chunks at once
@@ -576,6 +584,7 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint
       rc = merge_write(c, words, lo, hi, 0);
       if (rc) return rc;
     }
+    if (o.added && !fire) c->new_frac = (double)o.newd / (double)o.added;
     c->ndistinct += o.newd;
     c->nelts += o.added;
     st->kmers += o.added;

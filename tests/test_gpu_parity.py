@@ -186,3 +186,56 @@ def test_full_table_is_an_error_not_corruption():
     assert e.value.code in (-3, -4)
     assert ctx.blocks() == before
     ctx.close()
+
+
+def test_large_scale_properties(tmp_path):
+    """size-independent properties at a scale the oracle cannot replay insert by insert
+    (qb 26, ~100 M k-mers): the table does not depend on how the reads are cut into chunks
+    and calls; header counters equal what a decode of the exported .cqf finds; a second deNoise
+    round right after the first removes nothing; export -> import -> export is the identity."""
+    import hashlib
+    import importlib.util
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dev = torch.device("cuda", 0)
+    qb, K, L, R = 26, 47, 150, 1_000_000
+    genome = torch.randint(0, 4, (20_000_000,), device=dev, dtype=torch.uint8,
+                           generator=torch.Generator(device=dev).manual_seed(5))
+    text = bench.gen_batch_torch(torch, genome, R, L, 0.003, 0, 77, dev)
+    torch.cuda.synchronize()
+    rec = 2 * L + bench.NAME_W + 6
+    digests = []
+    for part, calls in ((1 << 23, 1), (1 << 21, 3)):
+        offs, lens = bench.chunk_table(R, rec, part, 65535 if part == 1 << 23 else 8191)
+        ctx = _ctx(qb=qb, k=K, max_batch_bytes=64, max_batch_keys=R * (L - K + 1) + 4096, max_batch_reads=R + 1024)
+        per = (len(offs) + calls - 1) // calls
+        tot = 0
+        for i in range(0, len(offs), per):
+            st = ctx.count_chunks(text.data_ptr(), offs[i:i + per], lens[i:i + per], on_device=True, text_bytes=text.numel())
+            tot += st["kmers"]
+        t = ctx.totals()
+        assert tot == t.nelts
+        digests.append((hashlib.sha256(ctx.blocks()).hexdigest(), t.nelts, t.ndistinct))
+        if calls == 1:
+            p = str(tmp_path / "big.cqf")
+            ctx.export_cqf(p)
+            o = cqflibs.oracle().load(p)     # decode with the CPU checker
+            assert o.check_offset()
+            d = o.dump()
+            assert len(d) == t.ndistinct and sum(c for _, c in d) == t.nelts
+            o.free()
+            r1 = ctx.denoise()
+            h1 = hashlib.sha256(ctx.blocks()).hexdigest()
+            r2 = ctx.denoise()
+            assert r1 > 0 and r2 == 0 and hashlib.sha256(ctx.blocks()).hexdigest() == h1
+            p2 = str(tmp_path / "big2.cqf")
+            ctx.export_cqf(p2)
+            ctx2 = _ctx(qb=qb, k=K, max_batch_bytes=64, max_batch_keys=4096)
+            ctx2.import_cqf(p2)
+            assert hashlib.sha256(ctx2.blocks()).hexdigest() == h1
+            ctx2.close()
+        ctx.close()
+    assert digests[0] == digests[1]
