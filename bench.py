@@ -217,8 +217,10 @@ def main():
     R = args.reads_per_step
     # README sizing; when the planned run presents more k-mers than the README's N (weak
     # scaling over several GPUs) the same formulas are applied to the planned total
-    N_plan = max(N_README, world * (args.steps + args.warmup) * R * (L - K + 1))
-    qb, nd, trigger = sizing(K, n_README, N_plan, ERR)
+    # Weak scaling: with G GPUs the data set is G times larger (G x the genome, G x the distinct true
+    # k-mers, G x the reads per step) and so is the filter, so every GPU keeps a C. elegans-sized shard.
+    N_plan = max(N_README * world, world * (args.steps + args.warmup) * R * (L - K + 1))
+    qb, nd, trigger = sizing(K, n_README * world, N_plan, ERR)
     if args.qb:
         qb = args.qb
     rec = 2 * L + NAME_W + 6
@@ -231,7 +233,7 @@ def main():
                       max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
     tot = ctx.totals()
 
-    genome = torch.randint(0, 4, (args.genome,), device=device, dtype=torch.uint8,
+    genome = torch.randint(0, 4, (args.genome * world,), device=device, dtype=torch.uint8,
                            generator=torch.Generator(device=device).manual_seed(2))
     nsteps = args.steps + args.warmup
     texts = [gen_batch_torch(torch, genome, R, L, ERR, (s * world + rank) * R, 1000 + s * world + rank, device)
@@ -258,10 +260,7 @@ def main():
             rounds_fired += st["denoise_rounds"]
             return
         dp, nw = ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
-        words = torch.as_tensor(_CAI(dp, nw), device=device)
-        # global chunk order: the ranks' parts interleave like the reference's file queue (CQF_mt.h:828-830)
-        words = (words & ((1 << hb) - 1)) | (((words >> hb) * world + rank) << hb)
-        recv = shkdist.route_words(words, hb, qb, world, device)
+        recv = shkdist.route_words(ctx, nw, hb, world, rank, device)
         torch.cuda.synchronize()
         ctx.stage_words(recv.data_ptr(), recv.numel())
         r = shkdist.sharded_count(ctx, sstate, len(offs) * world)
@@ -311,7 +310,7 @@ def main():
             "value": counted / dt, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C.elegans-like synthetic reads (G=%d, L=150, e=0.00234), k=47, CQF qb=%d hb=%d "
+            "config": {"workload": "C.elegans-like synthetic reads (G=%d x n_gpus, L=150, e=0.00234), k=47, CQF qb=%d hb=%d "
                                    "(README.md:98 sizing, N=%d), %d reads/step/GPU, 8 MiB chunks, deNoise rounds=%d trigger=%d"
                                    % (args.genome, qb, hb, N_plan, R, nd, trigger),
                        "kmers_per_step_per_gpu": R * kmers_per_read, "denoise_rounds_fired": rounds_fired,

@@ -109,6 +109,7 @@ int shk_count_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords, uint
  * the WHOLE filter, so with quotient-range shards the host reduces each shard's statistics
  * (all-reduce over RCCL/gloo) between these calls and takes the same decisions on every rank
  * (sh-assembly_amd/shk/dist.py mirrors the single-GPU logic of csrc/shk_api.hip merge_stage).
+ *   shk_route_words    bin this rank's key words by owner (send buffer of the all-to-all)
  *   shk_stage_words    copy + partition the routed key words (chunk ids are global)
  *   shk_stage_summary  statistics of inserting the words of chunks [lo, hi]; nothing is written
  *   shk_stage_commit   write them; must follow a summary over exactly [lo, hi]
@@ -122,6 +123,10 @@ typedef struct shk_summary {
 } shk_summary;
 #define SHK_SOFT_BITS 0x0Au     /* table full | region image exceeded: only final for a committed range */
 #define SHK_HASH_FULL_BIT 0x04u /* too many distinct new keys in one region: summarise fewer chunks */
+/* Group the key words left by shk_hash_chunks by owner shard (owner = top log2(nshards) bits of
+ * the quotient): `*d_out` (context-owned, valid until the next call) holds them owner by owner,
+ * counts[o] words for owner o -- the send buffer of the all-to-all. */
+int shk_route_words(shk_ctx *ctx, uint64_t nwords, uint32_t nshards, uint64_t **d_out, uint64_t *counts);
 int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                       int want_hist, shk_summary *out);

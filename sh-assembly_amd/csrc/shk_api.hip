@@ -198,7 +198,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
     uint64_t mx = capk > c->max_reads ? capk : c->max_reads;
     uint64_t pw = 1ULL << c->rbits;
     if (pw > mx) mx = pw;
-    if (dmalloc(&c->d_block_sums, mx / SHK_SCAN_TILE + 4)) return SHK_ERR_HIP;
+    if (dmalloc(&c->d_block_sums, mx / SHK_SCAN_TILE + 4 + 8192)) return SHK_ERR_HIP;
   }
   {
     uint64_t nb = 1;
@@ -667,6 +667,46 @@ extern "C" int shk_count_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwo
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
   return finish(c, rc);
+}
+
+extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, uint64_t **d_out, uint64_t *counts) {
+  if (!c || !d_out || !counts || nshards == 0 || (nshards & (nshards - 1)) || nshards > SHK_RP_MAXP) return SHK_ERR_ARG;
+  if (nwords > c->cfg.max_batch_keys) return SHK_ERR_BATCH;
+  HIPCHK(hipSetDevice(c->dev));
+  uint32_t lg = 0;
+  while ((1u << lg) < nshards) lg++;
+  if (lg == 0) { *d_out = c->d_words[0]; counts[0] = nwords; return SHK_OK; }
+  if (c->cfg.qb < SHK_REGION_LOG2 + lg) return SHK_ERR_ARG;
+  // one partition level over the WHOLE filter's regions: digit = owner
+  ShkRpLevel lv;
+  lv.shift = (c->cfg.qb - SHK_REGION_LOG2) - lg; lv.bits = lg; lv.nbuckets = 1; lv.hb = c->cfg.hb; lv.q_lo = 0;
+  c->h_pinned[43] = nwords;
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
+  const uint64_t *n_p = c->d_scalars + 1;
+  const uint32_t nwin = (uint32_t)(nwords / SHK_RP_TILE + 1);
+  uint64_t *hist = c->d_block_sums;            // scratch: nshards <= 1024 words each
+  uint64_t *base = c->d_block_sums + 2048;
+  uint64_t *cursor = c->d_block_sums + 4096;
+  { ProfScope ps(c, KP_RP_PREP);
+    hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]);
+    hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[0], 1u, n_p, c->d_tfb);
+    HIPCHK(hipMemsetAsync(hist, 0, nshards * 8, c->stream)); }
+  { ProfScope ps(c, KP_RP_HIST);
+    hipLaunchKernelGGL(k_rp_hist, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[0], n_p, c->d_base[0], c->d_tfb, lv, hist); }
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 16, hist, nshards * 8 > 16 * 8 ? 16 * 8 : nshards * 8, hipMemcpyDeviceToHost, c->stream));
+  std::vector<uint64_t> hh(nshards);
+  HIPCHK(hipMemcpyAsync(hh.data(), hist, nshards * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<uint64_t> bb(nshards + 1, 0);
+  for (uint32_t i = 0; i < nshards; i++) { counts[i] = hh[i]; bb[i + 1] = bb[i] + hh[i]; }
+  HIPCHK(hipMemcpyAsync(cursor, bb.data(), nshards * 8, hipMemcpyHostToDevice, c->stream));
+  (void)base;
+  { ProfScope ps(c, KP_RP_SCATTER);
+    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[0], c->d_words[1], n_p,
+                       c->d_base[0], c->d_tfb, lv, cursor); }
+  HIPCHK(hipGetLastError());
+  *d_out = c->d_words[1];
+  return finish(c, 0);
 }
 
 extern "C" int shk_stage_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwords) {

@@ -57,7 +57,7 @@ class ShkError(RuntimeError):
         self.code = code
 
 
-EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_stage_words",
+EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
            "shk_stage_summary", "shk_stage_commit", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -82,6 +82,7 @@ def load(path=None):
     L.shk_count_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(BatchStats)]
     L.shk_hash_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(vp), pu64]
     L.shk_count_words.argtypes = [vp, vp, u64, u32, C.POINTER(BatchStats)]
+    L.shk_route_words.argtypes = [vp, u64, u32, C.POINTER(vp), pu64]
     L.shk_stage_words.argtypes = [vp, vp, u64]
     L.shk_stage_summary.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
     L.shk_stage_commit.argtypes = [vp, u32, u32, C.POINTER(Summary)]
@@ -168,6 +169,7 @@ class Context:
             ptr, n = C.cast(buf, C.c_void_p), len(text)
         self._chk(self.L.shk_hash_chunks(self.h, ptr, 1 if on_device else 0, n, self._tab(chunk_off),
                                          self._tab(chunk_len), len(chunk_off), C.byref(dp), C.byref(nw)))
+        self._words_ptr = dp.value
         return dp.value, nw.value
 
     def count_words(self, d_words, nwords, nchunks=1):
@@ -175,6 +177,17 @@ class Context:
         self._chk(self.L.shk_count_words(self.h, C.c_void_p(int(d_words) if d_words else 0), nwords, nchunks,
                                          C.byref(st)))
         return st.as_dict()
+
+    def words_ptr(self):
+        """pointer of the buffer shk_hash_chunks fills (valid until the next call)"""
+        return self._words_ptr
+
+    def route_words(self, nwords, nshards):
+        """bin the words left by hash_chunks by owner; returns (device pointer, [count per owner])"""
+        dp = C.c_void_p()
+        cnt = (C.c_uint64 * nshards)()
+        self._chk(self.L.shk_route_words(self.h, nwords, nshards, C.byref(dp), cnt))
+        return dp.value, [cnt[i] for i in range(nshards)]
 
     def stage_words(self, d_words, nwords):
         self._chk(self.L.shk_stage_words(self.h, C.c_void_p(int(d_words) if d_words else 0), nwords))

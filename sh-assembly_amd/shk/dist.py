@@ -110,21 +110,43 @@ def sharded_count(ctx, st, nchunks):
 ROUTE_PIECE = 1 << 25   # elements per peer per exchange (256 MB of key words)
 
 
-def route_words(words, hb, qb, world, device):
-    """bin key words by owner = top log2(world) bits of the quotient and exchange them.
-    The exchange runs as a sequence of all-to-alls of at most ROUTE_PIECE words per peer: one
-    RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only its first
-    832 MB on this stack (tools/dbg_dist.py), and bounded pieces also bound the staging memory."""
-    shift = hb - (world.bit_length() - 1)
-    key = words & ((1 << hb) - 1)
-    owner = key >> shift
-    order = torch.argsort(owner)
-    send = words[order].contiguous()
-    send_counts = torch.bincount(owner, minlength=world)
+class _CAI:
+    """expose a raw device pointer to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+def wrap_words(ptr, n, device):
+    """int64 tensor view of n key words at a library-owned pointer (device memory on a GPU,
+    host memory in the CPU emulator build)"""
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=device)
+    if device.type == "cuda":
+        return torch.as_tensor(_CAI(ptr, n), device=device)
+    import ctypes
+    return torch.frombuffer((ctypes.c_int64 * n).from_address(ptr), dtype=torch.int64)
+
+
+def route_words(ctx, nwords, hb, world, rank, device):
+    """Exchange the key words shk_hash_chunks left in the context: chunk indices become global
+    (the ranks' parts interleave like the reference's file queue, cqf/CQF_mt.h:828-830), the library
+    bins them by owner (shk_route_words), and the bins travel in all-to-alls of at most ROUTE_PIECE
+    words per peer (one RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only
+    its first 832 MB on this stack; bounded pieces also bound the staging memory)."""
+    dp0 = ctx.words_ptr()
+    words = wrap_words(dp0, nwords, device)
+    if nwords:
+        words.copy_((words & ((1 << hb) - 1)) | (((words >> hb) * world + rank) << hb))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dp, sc = ctx.route_words(nwords, world)
+    send = wrap_words(dp, nwords, device)
+    send_counts = torch.tensor(sc, dtype=torch.int64, device=device)
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts)
-    sc, rc = send_counts.tolist(), recv_counts.tolist()
-    recv = torch.empty((sum(rc),), dtype=words.dtype, device=device)
+    rc = recv_counts.tolist()
+    recv = torch.empty((sum(rc),), dtype=torch.int64, device=device)
     mx = _allreduce([max(sc + rc)], device, dist.ReduceOp.MAX)[0]
     soff = [sum(sc[:p]) for p in range(world)]
     roff = [sum(rc[:p]) for p in range(world)]
@@ -135,7 +157,7 @@ def route_words(words, hb, qb, world, device):
             outs[0].copy_(ins[0])
             continue
         isz, osz = [int(x.numel()) for x in ins], [int(x.numel()) for x in outs]
-        piece = torch.empty((sum(osz),), dtype=words.dtype, device=device)
+        piece = torch.empty((sum(osz),), dtype=torch.int64, device=device)
         dist.all_to_all_single(piece, torch.cat(ins), output_split_sizes=osz, input_split_sizes=isz)
         o = 0
         for p in range(world):

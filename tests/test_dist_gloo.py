@@ -39,9 +39,7 @@ def _worker(rank, world, port, q):
     st = shkdist.ShardState(TRIG, ND, dev)
     hb = QB + 8
     dp, nw = ctx.hash_chunks(fq, offs, lens)
-    words = torch.frombuffer((C.c_int64 * nw).from_address(dp), dtype=torch.int64).clone()
-    words = (words & ((1 << hb) - 1)) | (((words >> hb) * world + rank) << hb)
-    recv = shkdist.route_words(words, hb, QB, world, dev)
+    recv = shkdist.route_words(ctx, nw, hb, world, rank, dev)
     ctx.stage_words(recv.data_ptr(), recv.numel())
     out = shkdist.sharded_count(ctx, st, len(offs) * world)
     # (key, count) content of this shard through lookups of every key it received
