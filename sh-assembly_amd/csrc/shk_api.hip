@@ -746,6 +746,30 @@ extern "C" int shk_stage_commit(shk_ctx *c, uint32_t lo, uint32_t hi, const shk_
   return finish(c, rc);
 }
 
+extern "C" int shk_stage_try(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t hist_base, uint32_t hist_shift, int want_hist,
+                             shk_summary *out) {
+  if (!c || !out || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  MergeOut o;
+  int rc;
+  if (c->single_ok) rc = merge_single(c, c->d_words[c->staged], lo, hi, 0, &o, want_hist, hist_base, hist_shift);
+  else { rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist); o.err |= SHK_E_LOOKBACK; }
+  prof_collect(c);
+  if (rc) return rc;
+  out->new_distinct = o.newd; out->added = o.added; out->removed = o.removed; out->before = o.before;
+  for (int i = 0; i < SHK_HIST_BINS; i++) out->hist[i] = o.hist[i];
+  out->err_bits = o.err; out->reserved = 0;
+  return SHK_OK;
+}
+
+extern "C" int shk_stage_accept(shk_ctx *c, const shk_summary *s) {
+  if (!c || !s) return SHK_ERR_ARG;
+  if (s->err_bits) return map_err_bits(s->err_bits);
+  commit_single(c);
+  c->ndistinct += s->new_distinct; c->nelts += s->added;
+  return SHK_OK;
+}
+
 extern "C" int shk_denoise(shk_ctx *c, uint64_t *removed) {
   if (!c) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));

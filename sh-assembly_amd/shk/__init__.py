@@ -44,6 +44,7 @@ class Summary(C.Structure):
 
 SOFT_BITS = 0x0A
 HASH_FULL_BIT = 0x04
+LOOKBACK_BIT = 0x100
 HIST_BINS = 32
 
 
@@ -58,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_denoise",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
            "shk_last_error_bits"]
@@ -86,6 +87,8 @@ def load(path=None):
     L.shk_stage_words.argtypes = [vp, vp, u64]
     L.shk_stage_summary.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
     L.shk_stage_commit.argtypes = [vp, u32, u32, C.POINTER(Summary)]
+    L.shk_stage_try.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
+    L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
     L.shk_denoise.argtypes = [vp, pu64]
     L.shk_stats.argtypes = [vp, C.POINTER(Totals)]
     L.shk_header.argtypes = [vp, C.c_char_p]
@@ -196,6 +199,14 @@ class Context:
         s = Summary()
         self._chk(self.L.shk_stage_summary(self.h, lo, hi, hist_base, hist_shift, 1 if want_hist else 0, C.byref(s)))
         return s
+
+    def stage_try(self, lo, hi, hist_base=0, hist_shift=0, want_hist=False):
+        s = Summary()
+        self._chk(self.L.shk_stage_try(self.h, lo, hi, hist_base, hist_shift, 1 if want_hist else 0, C.byref(s)))
+        return s
+
+    def stage_accept(self, summary):
+        self._chk(self.L.shk_stage_accept(self.h, C.byref(summary)))
 
     def stage_commit(self, lo, hi, summary):
         self._chk(self.L.shk_stage_commit(self.h, lo, hi, C.byref(summary)))

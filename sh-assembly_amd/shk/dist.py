@@ -8,7 +8,7 @@ shard -- the chunk at which the whole filter's distinct count reaches the trigge
 import torch
 import torch.distributed as dist
 
-from . import HASH_FULL_BIT, HIST_BINS, SOFT_BITS, ShkError
+from . import HASH_FULL_BIT, HIST_BINS, LOOKBACK_BIT, SOFT_BITS, ShkError
 
 
 class ShardState:
@@ -27,12 +27,13 @@ def _allreduce(vals, device, op=None):
     return [int(x) for x in t.tolist()]
 
 
-def _summary(ctx, st, lo, hi, base, shift, want_hist):
-    """local summary + reduction; returns (newd, before, hist[], hard_bits_any, hash_full_any, soft_any, local)"""
-    s = ctx.stage_summary(lo, hi, base, shift, want_hist)
+def _summary(ctx, st, lo, hi, base, shift, want_hist, single=False):
+    """local summary (or single-launch try) + reduction; returns
+    (newd, before, hist[], hard_bits_any, hash_full_any, soft_any, local)"""
+    s = ctx.stage_try(lo, hi, base, shift, want_hist) if single else ctx.stage_summary(lo, hi, base, shift, want_hist)
     red = _allreduce([s.new_distinct, s.before] + list(s.hist), st.device)
-    flags = _allreduce([s.err_bits & ~(SOFT_BITS | HASH_FULL_BIT) & 0xFFFFFFFF, s.err_bits & HASH_FULL_BIT,
-                        s.err_bits & SOFT_BITS], st.device, dist.ReduceOp.MAX)
+    flags = _allreduce([s.err_bits & ~(SOFT_BITS | HASH_FULL_BIT | LOOKBACK_BIT) & 0xFFFFFFFF,
+                        s.err_bits & (HASH_FULL_BIT | LOOKBACK_BIT), s.err_bits & SOFT_BITS], st.device, dist.ReduceOp.MAX)
     return red[0], red[1], red[2:], flags[0], flags[1], flags[2], s
 
 
@@ -43,6 +44,20 @@ def sharded_count(ctx, st, nchunks):
     while lo < nchunks:
         hi = nchunks - 1
         watch = st.rounds_left > 0
+        # common case: one launch per rank does statistics and table; accepted when no rank saw an
+        # error and the whole filter stays below the trigger
+        newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False, single=True)
+        if hard:
+            ctx.error_for_bits(hard)
+        if not (hfull or soft) and not (watch and st.ndistinct + newd >= st.trigger):
+            ctx.stage_accept(loc)
+            added = _allreduce([loc.added], st.device)[0]
+            st.ndistinct += newd
+            st.nelts += added
+            out["kmers"] += added
+            out["new_distinct"] += newd
+            lo = hi + 1
+            continue
         while True:
             span = hi - lo + 1
             shift = 0
@@ -86,10 +101,19 @@ def sharded_count(ctx, st, nchunks):
                 if hard:
                     ctx.error_for_bits(hard)
             fire = True
-            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False)
+            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False, single=True)
+            if not (hard or hfull or soft):
+                ctx.stage_accept(loc)
+                accepted = True
+            else:
+                accepted = False
+                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False)
+        else:
+            accepted = False
         if hard or hfull or soft:
             ctx.error_for_bits(hard | hfull | soft)
-        ctx.stage_commit(lo, hi, loc)
+        if not accepted:
+            ctx.stage_commit(lo, hi, loc)
         added = _allreduce([loc.added], st.device)[0]
         st.ndistinct += newd
         st.nelts += added
