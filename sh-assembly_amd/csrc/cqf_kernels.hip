@@ -130,9 +130,13 @@ __device__ __forceinline__ unsigned shk_img_dec_fast(const uint8_t *img, unsigne
 
 #define SHK_STAMP(i) do { if (A.dbg && (blockIdx.x & 63) == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&A.dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
 
-template <int MODE>
+template <int MODE, int IMGB>
 __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A) {
   constexpr bool WRITE = MODE != 0;
+  // LDS image of IMGB blocks: the region's own blocks + the blocks its runs may spill into.
+  // IMGB = IMG_BLOCKS normally; the host retries a pass with IMG_BLOCKS_BIG when a cluster is longer.
+  constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
+  static_assert(IMGB <= SHK_WAVE, "one lane per image block in the rank/select step");
   __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
   __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch
   __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
@@ -140,13 +144,13 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
   __shared__ uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
   __shared__ uint16_t rstart[SHK_REGION];
-  __shared__ __attribute__((aligned(16))) uint8_t oimg[SHK_IMG_BYTES + 16];
-  __shared__ __attribute__((aligned(16))) uint8_t nimg[SHK_IMG_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t oimg[IMG_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
   __shared__ uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_PER_LANE];
   __shared__ uint64_t oocc[SHK_REGION_BLOCKS];
-  __shared__ uint64_t orunw[SHK_IMG_BLOCKS];
+  __shared__ uint64_t orunw[IMG_BLOCKS];
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
-  __shared__ uint32_t orrank[SHK_IMG_BLOCKS + 1];
+  __shared__ uint32_t orrank[IMG_BLOCKS + 1];
   __shared__ uint32_t lhist[SHK_HIST_BINS];
   __shared__ uint32_t s_fail, s_added;
 
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   if (nblk_old < nown) nblk_old = nown;
   if (tid == 0) { s_fail = 0; s_added = 0; }
   bool fatal = false;
-  if (nblk_old > SHK_IMG_BLOCKS || ohi > SHK_IMG_SLOTS) {
+  if (nblk_old > IMG_BLOCKS || ohi > IMG_SLOTS) {
     if (tid == 0) atomicOr(A.err, SHK_E_OLD_EXTENT);
     fatal = true;
     nblk_old = nown;
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
-      for (uint32_t i = tid; i < (SHK_IMG_BYTES + 16) / 4; i += ngrp) z[i] = 0;
+      for (uint32_t i = tid; i < (IMG_BYTES + 16) / 4; i += ngrp) z[i] = 0;
     }
   }
   __syncthreads();
@@ -267,11 +271,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
     const uint32_t rc = (uint32_t)__popcll(rw);
     const uint32_t rinc = shk_wave_incl_add(rc);
-    if (tid < SHK_IMG_BLOCKS) { orrank[tid] = rinc - rc; orunw[tid] = rw; }
-    if (tid == SHK_WAVE - 1) orrank[SHK_IMG_BLOCKS] = rinc;
+    if (tid < IMG_BLOCKS) { orrank[tid] = rinc - rc; orunw[tid] = rw; }
+    if (tid == SHK_WAVE - 1) orrank[IMG_BLOCKS] = rinc;
   }
   __syncthreads();
-  const uint32_t nruns_old = orrank[SHK_IMG_BLOCKS];
+  const uint32_t nruns_old = orrank[IMG_BLOCKS];
   if (nruns_old != oorank[SHK_REGION_BLOCKS] || nruns_old > SHK_REGION) {
     if (tid == 0) atomicOr(A.err, SHK_E_CORRUPT);
     fatal = true;
@@ -279,7 +283,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // position of the j-th runend: one lane per run (select over the masked runends words)
   if (!fatal)
     for (uint32_t j = tid; j < nruns_old; j += nthr) {
-      uint32_t lo = 0, hi = SHK_IMG_BLOCKS;   // last word w with orrank[w] <= j
+      uint32_t lo = 0, hi = IMG_BLOCKS;   // last word w with orrank[w] <= j
       while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (orrank[mid] <= j) lo = mid; else hi = mid;
@@ -455,9 +459,9 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     // ---- single launch: look back over the regions before this one.
     // Every region publishes (T, c) as soon as it knows them (lb_agg) and its outgoing free
     // pointer once it knows its own incoming one (lb_incl). A window r'..r-1 composes to
-    // f -> max(f + a, b); since no region's runs may end more than SHK_IMG_SLOTS behind its
-    // start, f_in(r') <= start(r') + SHK_IMG_SLOTS - SHK_REGION, so the window already decides
-    // f_in(r) = b as soon as start(r') + SHK_IMG_SLOTS - SHK_REGION + a <= b.
+    // f -> max(f + a, b); since no region's runs may end more than IMG_SLOTS behind its
+    // start, f_in(r') <= start(r') + IMG_SLOTS - SHK_REGION, so the window already decides
+    // f_in(r) = b as soon as start(r') + IMG_SLOTS - SHK_REGION + a <= b.
     if (tid == 0) {
       const uint32_t c_rel = (!fatal && tot.b > 0) ? (uint32_t)tot.b : 0;
       __hip_atomic_store(&A.lb_agg[r], (unsigned long long)(SHK_LB_VALID | ((uint32_t)tot.a << 12)) << 32 | c_rel,
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         const uint32_t c_rel = (uint32_t)aw;
         m.b = c_rel ? rr_u * SHK_REGION + c_rel : SHK_NEG_INF;
         win = shk_mp_compose(m, win);      // farther region first, then what we had
-        const long long bound = rr_u * SHK_REGION + (SHK_IMG_SLOTS - SHK_REGION);
+        const long long bound = rr_u * SHK_REGION + (IMG_SLOTS - SHK_REGION);
         if (bound + win.a <= win.b) { f_in = win.b; done = true; break; }
       }
       if (!done) {
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (tid == 0) {
       A.finB[r + 1] = (uint64_t)f_out;
       if (r == 0) A.finB[0] = 0;
-      if (tot.a > 0 && f_out - (long long)q0 > SHK_IMG_SLOTS) atomicOr(A.err, SHK_E_NEW_EXTENT);
+      if (tot.a > 0 && f_out - (long long)q0 > IMG_SLOTS) atomicOr(A.err, SHK_E_NEW_EXTENT);
       if ((uint64_t)f_out > A.xnslots) atomicOr(A.err, SHK_E_TABLE_FULL);
     }
     fin_rel = f_in - (long long)q0;
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const uint32_t out_lo = fin_rel > 0 ? (uint32_t)fin_rel : 0;
   const bool new_any = tot.a > 0;
   const uint32_t out_hi = new_any ? (uint32_t)fout_rel : out_lo;
-  if (new_any && (fout_rel > SHK_IMG_SLOTS || fout_rel < 0)) {
+  if (new_any && (fout_rel > IMG_SLOTS || fout_rel < 0)) {
     if (tid == 0) atomicOr(A.err, SHK_E_NEW_EXTENT);
     return;
   }
@@ -732,7 +736,7 @@ __global__ void k_region_scan_b(const long long *tile_a, const long long *tile_b
 }
 // c: one workgroup per tile: fin[] for its regions + the capacity checks
 __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, const long long *tile_f, uint64_t xnslots,
-                                uint64_t *fin, unsigned long long *counters, uint32_t *err) {
+                                uint32_t img_slots, uint64_t *fin, unsigned long long *counters, uint32_t *err) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
   const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
@@ -750,7 +754,7 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
     const ShkMP m = shk_region_mp(summary, r, nregions);
     f = shk_mp_apply(m, f);
     fin[r + 1] = (uint64_t)f;
-    if (m.a > 0 && f - (long long)r * SHK_REGION > SHK_IMG_SLOTS) atomicOr(err, SHK_E_NEW_EXTENT);
+    if (m.a > 0 && f - (long long)r * SHK_REGION > (long long)img_slots) atomicOr(err, SHK_E_NEW_EXTENT);
     if ((uint64_t)f > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
   }
   // statistics of this tile's regions

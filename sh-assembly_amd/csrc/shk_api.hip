@@ -61,6 +61,7 @@ struct shk_ctx {
   uint32_t *d_summary;
   long long *d_tile_a, *d_tile_b, *d_tile_f;
   unsigned long long *d_lb_agg, *d_lb_incl;
+  int big_image;                // 1: rebuild kernels run with the SHK_IMG_BLOCKS_BIG image (set after a cluster outgrew the small one)
   int single_ok;                // 0 after the single-launch rebuild had to give up once (then the two-launch scheme is used)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
@@ -351,6 +352,14 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
   return SHK_OK;
 }
 
+template <int MODE>
+static void launch_merge(shk_ctx *c, const ShkMergeArgs &A) {
+  if (c->big_image)
+    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+  else
+    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+}
+
 struct MergeOut {
   uint64_t newd, added, removed, before;
   uint64_t hist[SHK_HIST_BINS];
@@ -378,13 +387,13 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SUM);
-    hipLaunchKernelGGL((k_region_merge<0>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
+    launch_merge<0>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
     hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
     hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
     hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
-                       c->xnslots, c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
+                       c->xnslots, (uint32_t)(c->big_image ? SHK_IMG_BLOCKS_BIG * 64 : SHK_IMG_SLOTS), c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
@@ -403,7 +412,7 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   fill_args(c, &A, words, lo, hi, 0, 0, denoise);
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_WRITE);
-    hipLaunchKernelGGL((k_region_merge<1>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
+    launch_merge<1>(c, A); }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   return SHK_OK;
@@ -421,7 +430,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_SINGLE);
-    hipLaunchKernelGGL((k_region_merge<2>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A); }
+    launch_merge<2>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
     hipLaunchKernelGGL(k_stats_reduce, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_counters); }
@@ -439,7 +448,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
 }
 static void commit_single(shk_ctx *c) { c->cur ^= 1; }
 
-static int denoise_round(shk_ctx *c, uint64_t *removed) {
+static int denoise_round_once(shk_ctx *c, uint64_t *removed) {
   uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
   { ProfScope ps(c, KP_MARKS);
     hipLaunchKernelGGL(k_denoise_marks, dim3(1), dim3(64), 0, c->stream, c->tab[c->cur], c->nslots, c->xnslots, c->nblocks,
@@ -466,14 +475,26 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
   return SHK_OK;
 }
 
+static int denoise_round(shk_ctx *c, uint64_t *removed) {
+  int rc = denoise_round_once(c, removed);
+  if (rc == SHK_ERR_REGION && !c->big_image && (c->last_err_bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT))) {
+    c->big_image = 1;
+    c->last_err_bits = 0;
+    rc = denoise_round_once(c, removed);
+  }
+  if (!rc) c->big_image = 0;   // the round thinned the table out: back to the small image
+  return rc;
+}
+
 // Insert the words of chunks [0, nchunks) (already partitioned in `words`), firing deNoise
 // rounds where the t = 1 reference would: after the first chunk at which
 // ndistinct >= trigger while rounds are left (CQF_mt.h:837, 860-869).
-static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint64_t nwords, shk_batch_stats *st) {
+static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint64_t nwords, shk_batch_stats *st,
+                            uint32_t *lo_io) {
   // A summary over chunks that will turn out to lie behind a deNoise point is speculative:
   // "table full"/"extent" raised by its free-pointer scan mean nothing then.
   const uint32_t soft = SHK_E_TABLE_FULL | SHK_E_NEW_EXTENT;
-  uint32_t lo = 0;
+  uint32_t &lo = *lo_io;
   while (lo < nchunks) {
     uint32_t hi = nchunks - 1;
     const bool watch = c->rounds_left > 0;
@@ -604,6 +625,20 @@ static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint
   return SHK_OK;
 }
 
+// A cluster longer than the small LDS image makes a pass fail with an extent flag before anything is
+// committed: the remaining chunks are then rebuilt with the big image (until the next deNoise round
+// thins the table out again).
+static int merge_stage(shk_ctx *c, const uint64_t *words, uint32_t nchunks, uint64_t nwords, shk_batch_stats *st) {
+  uint32_t lo = 0;
+  int rc = merge_stage_from(c, words, nchunks, nwords, st, &lo);
+  if (rc == SHK_ERR_REGION && !c->big_image && (c->last_err_bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT))) {
+    c->big_image = 1;
+    c->last_err_bits = 0;
+    rc = merge_stage_from(c, words, nchunks, nwords, st, &lo);
+  }
+  return rc;
+}
+
 static int finish(shk_ctx *c, int rc) {
   uint32_t bits = 0;
   int rc2 = fetch_err(c, &bits);
@@ -729,6 +764,10 @@ extern "C" int shk_stage_summary(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t 
   HIPCHK(hipSetDevice(c->dev));
   MergeOut o;
   int rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist);
+  if (!rc && !c->big_image && (o.err & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) && !(o.err & SHK_E_TABLE_FULL)) {
+    c->big_image = 1;   // a cluster outgrew the small LDS image: same range with the big one
+    rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist);
+  }
   prof_collect(c);
   if (rc) return rc;
   out->new_distinct = o.newd; out->added = o.added; out->removed = o.removed; out->before = o.before;
@@ -752,8 +791,12 @@ extern "C" int shk_stage_try(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t hist
   HIPCHK(hipSetDevice(c->dev));
   MergeOut o;
   int rc;
-  if (c->single_ok) rc = merge_single(c, c->d_words[c->staged], lo, hi, 0, &o, want_hist, hist_base, hist_shift);
-  else { rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist); o.err |= SHK_E_LOOKBACK; }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (c->single_ok) rc = merge_single(c, c->d_words[c->staged], lo, hi, 0, &o, want_hist, hist_base, hist_shift);
+    else { rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist); o.err |= SHK_E_LOOKBACK; }
+    if (rc || c->big_image || !(o.err & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) || (o.err & SHK_E_TABLE_FULL)) break;
+    c->big_image = 1;
+  }
   prof_collect(c);
   if (rc) return rc;
   out->new_distinct = o.newd; out->added = o.added; out->removed = o.removed; out->before = o.before;

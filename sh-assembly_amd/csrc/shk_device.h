@@ -19,6 +19,7 @@
 #define SHK_REGION_BLOCKS (SHK_REGION / 64)
 #define SHK_IMG_BLOCKS 24                              // LDS image: own 4 blocks + 20 spill blocks
 #define SHK_IMG_SLOTS (SHK_IMG_BLOCKS * 64)            // 1536 slots
+#define SHK_IMG_BLOCKS_BIG 64                          // retry size for longer clusters (4096 slots)
 #define SHK_IMG_BYTES (SHK_IMG_BLOCKS * SHK_BLOCK_BYTES)
 #define SHK_HCAP_LOG2 9
 #define SHK_HCAP (1u << SHK_HCAP_LOG2)                 // LDS hash capacity (distinct new keys per region)

@@ -146,3 +146,39 @@ def test_shards_stitch_to_single_table(shk):
     assert out.raw == want
     # the spill really crossed the boundary in the single table
     assert want[(half // 64) * 89] > 0
+
+
+def test_long_cluster_retries_with_big_image(shk):
+    """a cluster longer than the small LDS image (1536 slots) makes the first pass stop with an
+    extent flag before anything is committed; the library rebuilds with the big image and the
+    result is still the canonical table. Lookups walk the long cluster too."""
+    import random
+    from cqf_canon import build_blocks
+    rnd = random.Random(5)
+    qb = 13
+    tot = {}
+    for _ in range(900):
+        key = ((3000 + rnd.randrange(0, 64)) << 8) | rnd.randrange(256)
+        tot[key] = tot.get(key, 0) + rnd.choice([1, 2, 3, 200])
+    for _ in range(300):
+        key = (rnd.randrange(1 << qb) << 8) | rnd.randrange(256)
+        tot[key] = tot.get(key, 0) + 1
+    small = {k: min(c, 200) for k, c in tot.items()}
+    want = build_blocks(qb, qb + 8, small)
+    from cqf_canon import layout_used
+    runs = layout_used(qb, small)
+    # the clump's cluster really is longer than the small image
+    clump_end = max(e for q, s, e in runs if 3000 <= q < 3064)
+    assert clump_end - 3000 > 1536
+    ctx = _ctx(shk, qb=qb, k=21, max_batch_bytes=64, max_batch_keys=1 << 17)
+    # at most 512 distinct new keys may enter one 256-quotient region per pass: feed the clump in slices
+    keys = list(small)
+    for i in range(0, len(keys), 250):
+        part = [k for k in keys[i:i + 250] for _ in range(small[k])]
+        arr = (C.c_uint64 * len(part))(*part)
+        ctx.count_words(C.addressof(arr), len(part), 1)
+    assert ctx.blocks() == want
+    ks = list(small)[:300]
+    cnt, _ = ctx.lookup(ks, mode=2)
+    assert cnt == [small[k] for k in ks]
+    ctx.close()
