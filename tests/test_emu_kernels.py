@@ -32,10 +32,10 @@ def test_key_stream_is_reference_order(shk):
     """k_hash_reads emits exactly the keys reads_to_kmers would insert, in its order,
     including the 'N' restart rule, short reads and lower case"""
     O = cqflibs.oracle()
-    fq = synth.make_fastq(synth.make_genome(3000, 1), 100, 100, 0.01, seed=3, n_frac=0.25, short_frac=0.1,
+    fq = synth.make_fastq(synth.make_genome(3000, 1), 60, 100, 0.01, seed=3, n_frac=0.25, short_frac=0.1,
                           lower_frac=0.05)
-    offs, lens = chunks_by_records(fq, 45)
-    for k, qb in ((28, 12), (47, 12), (100, 12)):
+    offs, lens = chunks_by_records(fq, 25)
+    for k, qb in ((28, 12), (100, 12)):
         ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=1 << 20, max_batch_keys=1 << 16)
         dp, nw = ctx.hash_chunks(fq, offs, lens)
         words = (C.c_uint64 * max(nw, 1)).from_address(dp)
@@ -155,21 +155,21 @@ def test_long_cluster_retries_with_big_image(shk):
     import random
     from cqf_canon import build_blocks
     rnd = random.Random(5)
-    qb = 13
+    qb = 12
     tot = {}
-    for _ in range(900):
-        key = ((3000 + rnd.randrange(0, 64)) << 8) | rnd.randrange(256)
-        tot[key] = tot.get(key, 0) + rnd.choice([1, 2, 3, 200])
-    for _ in range(300):
+    for _ in range(560):
+        key = ((1800 + rnd.randrange(0, 64)) << 8) | rnd.randrange(256)
+        tot[key] = tot.get(key, 0) + rnd.choice([2, 3, 200, 20000])
+    for _ in range(100):
         key = (rnd.randrange(1 << qb) << 8) | rnd.randrange(256)
         tot[key] = tot.get(key, 0) + 1
-    small = {k: min(c, 200) for k, c in tot.items()}
+    small = {k: min(c, 300) for k, c in tot.items()}
     want = build_blocks(qb, qb + 8, small)
     from cqf_canon import layout_used
     runs = layout_used(qb, small)
     # the clump's cluster really is longer than the small image
-    clump_end = max(e for q, s, e in runs if 3000 <= q < 3064)
-    assert clump_end - 3000 > 1536
+    clump_end = max(e for q, s, e in runs if 1800 <= q < 1864)
+    assert clump_end - 1800 > 1536
     ctx = _ctx(shk, qb=qb, k=21, max_batch_bytes=64, max_batch_keys=1 << 17)
     # at most 512 distinct new keys may enter one 256-quotient region per pass: feed the clump in slices
     keys = list(small)
