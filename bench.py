@@ -324,7 +324,7 @@ def main():
                               "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)"},
             "kernel_ms": kern_ms,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             text_cpu = texts[args.warmup].cpu().numpy().tobytes()
             out["cpu_baseline"] = cpu_baseline(torch, text_cpu, offs, lens, K, qb)
         print(json.dumps(out))
