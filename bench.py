@@ -303,6 +303,7 @@ def main():
         units_per_launch = per_rank_kmers / max(launches, 1)
         achieved = ALGO_BYTES_PER_KMER * units_per_launch / avg_s / 1e9
         kern_ms = {k: round(v[1], 3) for k, v in prof.items()}
+        kern_n = {k: int(v[0]) for k, v in prof.items()}
         table_bytes = tot.table_bytes
         path_bytes = ALGO_BYTES_PER_KMER * per_rank_kmers + rounds_fired * 2 * table_bytes
         out = {
@@ -322,7 +323,7 @@ def main():
             "roofline_path": {"achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                               "frac": path_bytes / dt / HBM_PEAK,
                               "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)"},
-            "kernel_ms": kern_ms,
+            "kernel_ms": kern_ms, "kernel_launches": kern_n,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             text_cpu = texts[args.warmup].cpu().numpy().tobytes()

@@ -18,7 +18,9 @@
 #include "shk_device.h"
 
 #define SHK_EMPTY 0xFFFFFFFFu
-#define SHK_SUM_STRIDE 6
+#define SHK_SUM_STRIDE 8
+#define SHK_SPILL_LENS SHK_REGION                                   // one length byte per quotient
+#define SHK_SPILL_STRIDE (SHK_SPILL_LENS + SHK_WAVE * 40)          // + the lanes' staged run bytes, packed
 #define SHK_RSCAN_TILE 4096
 
 struct ShkMergeArgs {
@@ -44,6 +46,12 @@ struct ShkMergeArgs {
   unsigned long long *lb_incl;    // [nregions]
   unsigned long long *dbg;        // diagnostics only: per-phase cycle sums of sampled regions (null = off)
   uint32_t ablate;                // diagnostics only (SHK_ABLATE): skip phases to time them; results invalid
+  // spill scheme (MODE 3 -> k_region_scan_* -> k_region_place): the summary launch keeps every region's
+  // run lengths and encoded bytes so that the second launch only places them
+  uint8_t *spill;                 // [nregions * SHK_SPILL_STRIDE]
+  uint32_t *over_list;            // regions whose runs did not fit the spill record (rebuilt by MODE 1 from this list)
+  unsigned long long *n_over;
+  const uint32_t *list;           // MODE 1 only: regions to rebuild (null = all, region = blockIdx.x)
 };
 
 __device__ __forceinline__ unsigned shk_img_slot_off(unsigned p) {
@@ -121,8 +129,66 @@ __device__ __forceinline__ unsigned shk_img_dec_fast(const uint8_t *img, unsigne
   return shk_img_dec(img, pos, run_end, rem_out, count);
 }
 
+// ---- image -> table B (shared by the rebuild kernel's write modes and k_region_place)
+template <int IMGB>
+__device__ __forceinline__ void shk_store_image(const ShkMergeArgs &A, uint32_t r, uint32_t nregions, const uint8_t *nimg,
+                                                unsigned tid, uint32_t nown, uint64_t b0, uint64_t q0, uint32_t out_lo,
+                                                uint32_t out_hi, bool new_any, long long fout_rel) {
+  // blocks past the last quotient hold only spilled runs: their offset bytes come from the
+  // final free pointer and are written by the last region's wave
+  if (r == nregions - 1) {
+    const long long fend = fout_rel + (long long)q0;
+    for (uint64_t b = A.nslots / 64 + tid; b < A.nblocks; b += SHK_WAVE) {
+      long long o = fend - (long long)(64 * b);
+      A.tabB[b * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+    }
+  }
+
+  // ---- image -> table B. Own blocks: offset byte + occupieds. Slots and runends bytes of
+  // [out_lo, out_hi) only; the first and last runends byte may be shared with the
+  // neighbouring regions' runs, so they are OR-ed in atomically (B was zeroed).
+  uint8_t *tb = A.tabB + b0 * SHK_BLOCK_BYTES;
+  // When no earlier region spills into this one, the own blocks are written whole with
+  // dword stores (a full region's own blocks are 356 contiguous, 4-byte aligned bytes).
+  uint32_t vblk = nown;
+  if (new_any && out_lo == 0 && (nown * SHK_BLOCK_BYTES) % 4 == 0) {
+    vblk = 0;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(nimg);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(tb);
+    for (uint32_t i = tid; i < nown * SHK_BLOCK_BYTES / 4; i += SHK_WAVE) dst[i] = src[i];
+  }
+  // the blocks before vblk: offset byte + occupieds always, slots/runends only where owned
+  for (uint32_t i = tid; i < vblk * 9; i += SHK_WAVE) {
+    const uint32_t blk = i / 9, byte = i % 9;
+    tb[blk * SHK_BLOCK_BYTES + byte] = nimg[blk * SHK_BLOCK_BYTES + byte];
+  }
+  if (out_hi > out_lo) {
+    // slots [out_lo, out_hi) minus what the dword stores covered ([vblk*64, nown*64))
+    const uint32_t va = vblk * 64, vb = nown * 64;
+    for (uint32_t p = out_lo + tid; p < out_hi; p += SHK_WAVE)
+      if (p < va || p >= vb || vblk == nown) tb[shk_img_slot_off(p)] = nimg[shk_img_slot_off(p)];
+    const uint32_t m0 = out_lo >> 3, m1 = (out_hi - 1) >> 3;
+    for (uint32_t m = m0 + tid; m <= m1; m += SHK_WAVE) {
+      const uint32_t bo = (m >> 3) * SHK_BLOCK_BYTES + SHK_OFF_RUN + (m & 7);
+      const uint8_t v = nimg[bo];
+      if (vblk < nown && (m >> 3) >= vblk && (m >> 3) < nown) continue;  // written by the dword stores
+      if (m == m0 || m == m1) {
+        if (v) {
+          uint8_t *addr = tb + bo;
+          uintptr_t ai = reinterpret_cast<uintptr_t>(addr);
+          uint32_t *w = reinterpret_cast<uint32_t *>(ai & ~(uintptr_t)3);
+          atomicOr(w, (uint32_t)v << ((ai & 3) << 3));
+        }
+      } else {
+        tb[bo] = v;
+      }
+    }
+  }
+}
+
 // MODE 0: summary (lengths + statistics). MODE 1: write pass of the two-launch scheme
-// (free pointers come from k_region_scan_*). MODE 2: single launch -- the wave obtains its
+// (free pointers come from k_region_scan_*). MODE 3: summary that also spills the run lengths
+// and encodings for k_region_place. MODE 2: single launch -- the wave obtains its
 // free pointer by looking back at the regions before it (see k_region_merge docs below).
 #define SHK_STAGE_PER_LANE 40   // bytes of encoded run kept per lane between the length pass and placement
 #define SHK_LB_VALID 0x80000000u
@@ -132,7 +198,8 @@ __device__ __forceinline__ unsigned shk_img_dec_fast(const uint8_t *img, unsigne
 
 template <int MODE, int IMGB>
 __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A) {
-  constexpr bool WRITE = MODE != 0;
+  constexpr bool WRITE = MODE == 1 || MODE == 2;   // builds the image and stores table B
+  constexpr bool STAGE = WRITE || MODE == 3;       // keeps the runs' encodings per lane
   // LDS image of IMGB blocks: the region's own blocks + the blocks its runs may spill into.
   // IMGB = IMG_BLOCKS normally; the host retries a pass with IMG_BLOCKS_BIG when a cluster is longer.
   constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
@@ -158,7 +225,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const unsigned tid = threadIdx.x;
   const unsigned ngrp = blockDim.x;              // all waves of the group: staging, init, key folding
   constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave does the rest
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = (MODE == 1 && A.list) ? A.list[blockIdx.x] : blockIdx.x;
+  const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
   const uint32_t nown = (nq + 63) / 64;
@@ -390,7 +458,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           }
         }
         const unsigned el = shk_enc_len_fast(rem, total);
-        if (WRITE) {
+        if (STAGE) {
           if (!st_over && st_used + el <= SHK_STAGE_PER_LANE) {
             if (total <= 128) {           // fast encode
               mystage[st_used] = (uint8_t)rem;
@@ -448,6 +516,29 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (A.want_hist && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
   }
   SHK_STAMP(5);   // scan + statistics
+  if (MODE == 3) {
+    // spill: 4 length bytes per lane, then the lanes' staged bytes back to back
+    uint8_t *sp = A.spill + (size_t)r * SHK_SPILL_STRIDE;
+    uint32_t l4 = 0;
+    bool big = st_over;
+#pragma unroll
+    for (uint32_t j = 0; j < per; j++) {
+      const uint32_t len = qcnt[qa + j];
+      if (len > 255) big = true;
+      l4 |= (len & 255u) << (8 * j);
+    }
+    reinterpret_cast<uint32_t *>(sp)[tid] = l4;
+    const bool over = !fatal && __ballot(big) != 0;
+    if (tid == 0) {
+      A.summary[(size_t)SHK_SUM_STRIDE * r + 6] = over ? 1 : 0;
+      if (over) A.over_list[atomicAdd(A.n_over, 1ULL)] = r;
+    }
+    if (!over) {
+      const uint32_t ex = shk_wave_incl_add(st_used) - st_used;
+      for (uint32_t i = 0; i < st_used; i++) sp[SHK_SPILL_LENS + ex + i] = mystage[i];
+    }
+    return;
+  }
   if (MODE == 0 || (A.ablate & 128)) return;
 
   // ================= placement =================
@@ -625,58 +716,104 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __syncthreads();
 
   SHK_STAMP(7);   // placement into the image
-  // blocks past the last quotient hold only spilled runs: their offset bytes come from the
-  // final free pointer and are written by the last region's wave
-  if (r == gridDim.x - 1) {
-    const long long fend = fout_rel + (long long)q0;
-    for (uint64_t b = A.nslots / 64 + tid; b < A.nblocks; b += nthr) {
-      long long o = fend - (long long)(64 * b);
-      A.tabB[b * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+  if (A.ablate & 8) return;
+  shk_store_image<IMGB>(A, r, nregions, nimg, tid, nown, b0, q0, out_lo, out_hi, new_any, fout_rel);
+  SHK_STAMP(8);   // stores to table B
+}
+
+// Second launch of the spill scheme: one wave per region places the spilled run bytes from the
+// region's free pointer (k_region_scan_*) into an LDS image of its blocks and stores table B.
+// Regions flagged in the summary (runs too long for the spill record) are left to MODE 1.
+template <int IMGB>
+__global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
+  constexpr unsigned IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
+  __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t pack[SHK_WAVE * 40];
+  const unsigned tid = threadIdx.x;
+  const uint32_t r = blockIdx.x;
+  const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
+  const uint32_t *sm = A.summary + (size_t)SHK_SUM_STRIDE * r;
+  if (sm[6]) return;
+  const uint64_t q0 = (uint64_t)r * SHK_REGION;
+  const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
+  const uint32_t nown = (nq + 63) / 64;
+  const uint64_t b0 = q0 / 64;
+  const bool new_any = sm[0] > 0;
+  const long long fin_rel = (long long)A.finB[r] - (long long)q0;
+  const long long fout_rel = (long long)A.finB[r + 1] - (long long)q0;
+  if (new_any && (fout_rel > IMG_SLOTS || fout_rel < 0)) {
+    if (tid == 0) atomicOr(A.err, SHK_E_NEW_EXTENT);
+    return;
+  }
+  const uint8_t *sp = A.spill + (size_t)r * SHK_SPILL_STRIDE;
+  const uint32_t l4 = reinterpret_cast<const uint32_t *>(sp)[tid];
+  {
+    uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
+    for (uint32_t i = tid; i < (IMG_BYTES + 16) / 4; i += SHK_WAVE) z[i] = 0;
+  }
+  constexpr uint32_t per = SHK_REGION / SHK_WAVE;
+  const uint32_t qa = tid * per;
+  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  uint32_t st_used = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t len = (l4 >> (8 * j)) & 255u;
+    if (len) {
+      ShkMP m; m.a = len; m.b = (long long)(qa + j) + len;
+      mine = shk_mp_compose(mine, m);
+      st_used += len;
     }
   }
-
-  // ---- image -> table B. Own blocks: offset byte + occupieds. Slots and runends bytes of
-  // [out_lo, out_hi) only; the first and last runends byte may be shared with the
-  // neighbouring regions' runs, so they are OR-ed in atomically (B was zeroed).
-  uint8_t *tb = A.tabB + b0 * SHK_BLOCK_BYTES;
-  if (A.ablate & 8) return;
-  // When no earlier region spills into this one, the own blocks are written whole with
-  // dword stores (a full region's own blocks are 356 contiguous, 4-byte aligned bytes).
-  uint32_t vblk = nown;
-  if (new_any && out_lo == 0 && (nown * SHK_BLOCK_BYTES) % 4 == 0) {
-    vblk = 0;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(nimg);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(tb);
-    for (uint32_t i = tid; i < nown * SHK_BLOCK_BYTES / 4; i += nthr) dst[i] = src[i];
+  ShkMP incl = mine;
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    ShkMP y;
+    y.a = __shfl_up(incl.a, d);
+    y.b = __shfl_up(incl.b, d);
+    if (tid >= (unsigned)d) incl = shk_mp_compose(y, incl);
   }
-  // the blocks before vblk: offset byte + occupieds always, slots/runends only where owned
-  for (uint32_t i = tid; i < vblk * 9; i += nthr) {
-    const uint32_t blk = i / 9, byte = i % 9;
-    tb[blk * SHK_BLOCK_BYTES + byte] = nimg[blk * SHK_BLOCK_BYTES + byte];
+  ShkMP pre;
+  pre.a = __shfl_up(incl.a, 1);
+  pre.b = __shfl_up(incl.b, 1);
+  if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
+  const uint32_t sinc = shk_wave_incl_add(st_used);
+  const uint32_t ex = sinc - st_used;
+  const uint32_t total = __shfl(sinc, SHK_WAVE - 1);
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sp + SHK_SPILL_LENS);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(pack);
+    for (uint32_t i = tid; i < (total + 3) / 4; i += SHK_WAVE) dst[i] = src[i];
   }
-  if (out_hi > out_lo) {
-    // slots [out_lo, out_hi) minus what the dword stores covered ([vblk*64, nown*64))
-    const uint32_t va = vblk * 64, vb = nown * 64;
-    for (uint32_t p = out_lo + tid; p < out_hi; p += nthr)
-      if (p < va || p >= vb || vblk == nown) tb[shk_img_slot_off(p)] = nimg[shk_img_slot_off(p)];
-    const uint32_t m0 = out_lo >> 3, m1 = (out_hi - 1) >> 3;
-    for (uint32_t m = m0 + tid; m <= m1; m += nthr) {
-      const uint32_t bo = (m >> 3) * SHK_BLOCK_BYTES + SHK_OFF_RUN + (m & 7);
-      const uint8_t v = nimg[bo];
-      if (vblk < nown && (m >> 3) >= vblk && (m >> 3) < nown) continue;  // written by the dword stores
-      if (m == m0 || m == m1) {
-        if (v) {
-          uint8_t *addr = tb + bo;
-          uintptr_t ai = reinterpret_cast<uintptr_t>(addr);
-          uint32_t *w = reinterpret_cast<uint32_t *>(ai & ~(uintptr_t)3);
-          atomicOr(w, (uint32_t)v << ((ai & 3) << 3));
-        }
-      } else {
-        tb[bo] = v;
+  __syncthreads();
+  const uint32_t out_lo = fin_rel > 0 ? (uint32_t)fin_rel : 0;
+  const uint32_t out_hi = new_any ? (uint32_t)fout_rel : out_lo;
+  uint32_t *nimg32 = reinterpret_cast<uint32_t *>(nimg);
+  {
+    long long f = shk_mp_apply(pre, fin_rel);
+    uint32_t so = ex;
+#pragma unroll
+    for (uint32_t j = 0; j < per; j++) {
+      const uint32_t q = qa + j;
+      if (q < nq && (q & 63) == 0) {
+        long long o = f - (long long)q;   // block_offset_strict, gqf.c:599-601, saturating like the 8-bit field
+        nimg[(q >> 6) * SHK_BLOCK_BYTES] = (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+      }
+      const uint32_t len = (l4 >> (8 * j)) & 255u;
+      if (len) {
+        const long long stt = f > (long long)q ? f : (long long)q;
+        f = stt + len;
+        const uint32_t wp = (uint32_t)stt;
+        for (uint32_t i = 0; i < len; i++) nimg[shk_img_slot_off(wp + i)] = pack[so + i];
+        so += len;
+        const uint32_t last = wp + len - 1;
+        const uint32_t bo = (last >> 6) * SHK_BLOCK_BYTES + SHK_OFF_RUN + ((last & 63) >> 3);
+        atomicOr(&nimg32[bo >> 2], 1u << (((bo & 3) << 3) + (last & 7)));
+        const uint32_t oo = (q >> 6) * SHK_BLOCK_BYTES + SHK_OFF_OCC + ((q & 63) >> 3);
+        atomicOr(&nimg32[oo >> 2], 1u << (((oo & 3) << 3) + (q & 7)));
       }
     }
   }
-  SHK_STAMP(8);   // stores to table B
+  __syncthreads();
+  shk_store_image<IMGB>(A, r, nregions, nimg, tid, nown, b0, q0, out_lo, out_hi, new_any, fout_rel);
 }
 
 // statistics of a single-launch rebuild (MODE 2): sum the per-region records

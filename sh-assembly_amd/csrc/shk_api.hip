@@ -19,12 +19,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_denoise_marks", "k_lookup", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -62,7 +62,13 @@ struct shk_ctx {
   long long *d_tile_a, *d_tile_b, *d_tile_f;
   unsigned long long *d_lb_agg, *d_lb_incl;
   int big_image;                // 1: rebuild kernels run with the SHK_IMG_BLOCKS_BIG image (set after a cluster outgrew the small one)
-  int single_ok;                // 0 after the single-launch rebuild had to give up once (then the two-launch scheme is used)
+  int single_ok;                // 1: single-launch rebuild with look-back (SHK_SINGLE=1); 0 after it had to give up once
+  int use_spill;                // 1 (default): summary launch spills lengths + encodings, k_region_place writes table B
+  uint8_t *d_spill;
+  uint32_t *d_over_list;
+  // what the spill records currently describe (a write pass may use them only for the same request)
+  int spill_valid; const uint64_t *spill_words; uint32_t spill_lo, spill_hi; int spill_denoise, spill_big;
+  uint64_t spill_nover;
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -214,10 +220,12 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (dmalloc(&c->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_summary, SHK_SUM_STRIDE * (uint64_t)c->nregions + 8)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_lb_agg, (uint64_t)c->nregions + 2) || dmalloc(&c->d_lb_incl, (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
-  c->single_ok = getenv("SHK_TWO_LAUNCH") ? 0 : 1;
+  c->single_ok = getenv("SHK_SINGLE") ? 1 : 0;
+  c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
+  if (dmalloc(&c->d_spill, (uint64_t)c->nregions * SHK_SPILL_STRIDE) || dmalloc(&c->d_over_list, (uint64_t)c->nregions + 1)) return SHK_ERR_HIP;
   { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
     if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
-  if (dmalloc(&c->d_counters, 4 + SHK_HIST_BINS)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_counters, 4 + SHK_HIST_BINS + 4)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_err, 4)) return SHK_ERR_HIP;
   HIPCHK(hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
   HIPCHK(hipMemsetAsync(c->tab[0], 0, c->table_bytes + SHK_SLACK, c->stream));
@@ -249,7 +257,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
-  hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
+  hipFree(c->d_spill); hipFree(c->d_over_list); hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
   hipHostFree(c->h_pinned);
   hipStreamDestroy(c->stream);
   delete c;
@@ -377,16 +385,21 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
   A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
   A->dbg = getenv("SHK_STAMPS") ? (unsigned long long *)(c->d_scalars + 16) : nullptr;
+  A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
 // summary launch + free-pointer scan, then read the statistics back (one synchronisation)
 static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase, uint32_t hshift,
-                         int denoise, MergeOut *o, int want_hist = 0) {
+                         int denoise, MergeOut *o, int want_hist = 0, int spill = 0) {
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, hbase, hshift, denoise, want_hist);
-  HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS) * 8, c->stream));
-  { ProfScope ps(c, KP_MERGE_SUM);
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
+  spill = spill && c->use_spill;
+  c->spill_valid = 0;
+  if (spill) { ProfScope ps(c, KP_MERGE_SPILL);
+    launch_merge<3>(c, A); }
+  else { ProfScope ps(c, KP_MERGE_SUM);
     launch_merge<0>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
     const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
@@ -395,7 +408,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
     hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
                        c->xnslots, (uint32_t)(c->big_image ? SHK_IMG_BLOCKS_BIG * 64 : SHK_IMG_SLOTS), c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   o->newd = c->h_pinned[0]; o->added = c->h_pinned[1]; o->removed = c->h_pinned[2]; o->before = c->h_pinned[3];
@@ -403,6 +416,10 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   o->err = *(uint32_t *)(c->h_pinned + 40);
   if (o->err) c->last_err_bits = o->err;
   if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  if (spill && !o->err) {
+    c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = denoise;
+    c->spill_big = c->big_image; c->spill_nover = c->h_pinned[4 + SHK_HIST_BINS];
+  }
   return SHK_OK;
 }
 
@@ -411,8 +428,25 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, 0, 0, denoise);
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
-  { ProfScope ps(c, KP_MERGE_WRITE);
-    launch_merge<1>(c, A); }
+  if (c->spill_valid && c->spill_words == words && c->spill_lo == lo && c->spill_hi == hi && c->spill_denoise == denoise &&
+      c->spill_big == c->big_image) {
+    // the summary launch left lengths and encodings behind: placement only
+    { ProfScope ps(c, KP_PLACE);
+      if (c->big_image) hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A);
+      else hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A); }
+    if (c->spill_nover) {
+      A.list = c->d_over_list;
+      ProfScope ps(c, KP_MERGE_WRITE);
+      if (c->big_image)
+        hipLaunchKernelGGL((k_region_merge<1, SHK_IMG_BLOCKS_BIG>), dim3((uint32_t)c->spill_nover), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+      else
+        hipLaunchKernelGGL((k_region_merge<1, SHK_IMG_BLOCKS>), dim3((uint32_t)c->spill_nover), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+    }
+  } else {
+    ProfScope ps(c, KP_MERGE_WRITE);
+    launch_merge<1>(c, A);
+  }
+  c->spill_valid = 0;
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   return SHK_OK;
@@ -429,6 +463,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemsetAsync(c->d_lb_agg, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
+  c->spill_valid = 0;
   { ProfScope ps(c, KP_MERGE_SINGLE);
     launch_merge<2>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
@@ -463,7 +498,7 @@ static int denoise_round_once(shk_ctx *c, uint64_t *removed) {
     else if (!(o.err & SHK_E_LOOKBACK)) return map_err_bits(o.err);
   }
   if (!done) {
-    rc = merge_summary(c, nullptr, 0, 0, 0, 0, 1, &o);
+    rc = merge_summary(c, nullptr, 0, 0, 0, 0, 1, &o, 0, 1);
     if (rc) return rc;
     if (o.err) return map_err_bits(o.err);
     rc = merge_write(c, nullptr, 0, 0, 1);
@@ -512,11 +547,11 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
     const bool likely = watch && c->new_frac > 0 &&
                         (double)c->ndistinct + 0.8 * c->new_frac * (double)nwords * (double)(hi - lo + 1) / (double)nchunks >=
                             (double)c->cfg.ndistinct_for_denoise;
+    // When the trigger is within reach of this batch the first launch also fills the first-chunk
+    // histogram, so that a pass which turns out to contain the deNoise point already yields its coarse position.
+    const bool possible = watch && c->ndistinct + nwords >= c->cfg.ndistinct_for_denoise;
     if (c->single_ok && !likely) {
-      // common case: no deNoise point inside [lo, hi] -> one launch does statistics and table.
-      // When the trigger is within reach of this batch the same launch also fills the
-      // first-chunk histogram, so a discarded pass still yields the coarse position.
-      const bool possible = watch && c->ndistinct + nwords >= c->cfg.ndistinct_for_denoise;
+      // single-launch scheme: one launch does statistics and table
       rc = merge_single(c, words, lo, hi, 0, &o, possible ? 1 : 0, lo, shift);
       have_hist = possible && !(o.err & ~soft);
       if (rc) return rc;
@@ -538,9 +573,10 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
       uint32_t span = hi - lo + 1;
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
-      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, likely ? 1 : 0);
+      const int wh = (likely || (possible && c->use_spill)) ? 1 : 0;
+      rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, wh, 1);
       if (rc) return rc;
-      if (likely && !(o.err & ~soft)) have_hist = true;
+      if (wh && !(o.err & ~soft)) have_hist = true;
       if (o.err & ~(soft | SHK_E_HASH_FULL)) return map_err_bits(o.err & ~(soft | SHK_E_HASH_FULL));
       if (o.err & SHK_E_HASH_FULL) {
         // more distinct new keys in one region than its LDS hash holds: take fewer chunks at once
@@ -591,7 +627,7 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
         else if (!(o.err & SHK_E_LOOKBACK)) return map_err_bits(o.err);
       }
       if (!written) {
-        rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o);
+        rc = merge_summary(c, words, lo, hi, lo, 0, 0, &o, 0, 1);
         if (rc) return rc;
         if (o.err) return map_err_bits(o.err);
         rc = merge_write(c, words, lo, hi, 0);
@@ -763,10 +799,10 @@ extern "C" int shk_stage_summary(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t 
   if (!c || !out || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   MergeOut o;
-  int rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist);
+  int rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist, 1);
   if (!rc && !c->big_image && (o.err & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) && !(o.err & SHK_E_TABLE_FULL)) {
     c->big_image = 1;   // a cluster outgrew the small LDS image: same range with the big one
-    rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist);
+    rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist, 1);
   }
   prof_collect(c);
   if (rc) return rc;
@@ -793,7 +829,10 @@ extern "C" int shk_stage_try(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t hist
   int rc;
   for (int attempt = 0; attempt < 2; attempt++) {
     if (c->single_ok) rc = merge_single(c, c->d_words[c->staged], lo, hi, 0, &o, want_hist, hist_base, hist_shift);
-    else { rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist); o.err |= SHK_E_LOOKBACK; }
+    else {
+      rc = merge_summary(c, c->d_words[c->staged], lo, hi, hist_base, hist_shift, 0, &o, want_hist, 1);
+      if (!c->use_spill) o.err |= SHK_E_LOOKBACK;   // plain two-launch scheme: the caller commits through shk_stage_commit
+    }
     if (rc || c->big_image || !(o.err & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) || (o.err & SHK_E_TABLE_FULL)) break;
     c->big_image = 1;
   }
@@ -808,9 +847,15 @@ extern "C" int shk_stage_try(shk_ctx *c, uint32_t lo, uint32_t hi, uint32_t hist
 extern "C" int shk_stage_accept(shk_ctx *c, const shk_summary *s) {
   if (!c || !s) return SHK_ERR_ARG;
   if (s->err_bits) return map_err_bits(s->err_bits);
-  commit_single(c);
+  HIPCHK(hipSetDevice(c->dev));
+  if (c->single_ok) commit_single(c);
+  else {
+    if (!c->spill_valid) return SHK_ERR_ARG;   // nothing was tried
+    int rc = merge_write(c, c->spill_words, c->spill_lo, c->spill_hi, 0);
+    if (rc) return finish(c, rc);
+  }
   c->ndistinct += s->new_distinct; c->nelts += s->added;
-  return SHK_OK;
+  return finish(c, SHK_OK);
 }
 
 extern "C" int shk_denoise(shk_ctx *c, uint64_t *removed) {
