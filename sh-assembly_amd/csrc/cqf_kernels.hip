@@ -52,6 +52,7 @@ struct ShkMergeArgs {
   uint32_t *over_list;            // regions whose runs did not fit the spill record (rebuilt by MODE 1 from this list)
   unsigned long long *n_over;
   const uint32_t *list;           // MODE 1 only: regions to rebuild (null = all, region = blockIdx.x)
+  uint16_t *newchunks;            // [nregions * SHK_HCAP] first chunk of every NEW key of the region (null = off; needs want_hist)
 };
 
 __device__ __forceinline__ unsigned shk_img_slot_off(unsigned p) {
@@ -428,6 +429,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       while (ohas || ni < ne) {
         uint32_t rem; uint64_t total; bool is_new = false; bool prot = false; uint32_t mc = 0;
         bool adv = false;
+        uint32_t nhx = 0;
         if (ohas && orem <= nrem) {
           rem = orem; total = ocnt;
           if (A.denoise) {
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           opos += on;
           if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt); else ohas = false;
         } else {
-          rem = nrem; total = hcnt[nh]; is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); adv = true;
+          rem = nrem; total = hcnt[nh]; is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); adv = true; nhx = nh;
         }
         if (adv) {
           ni++;
@@ -450,6 +452,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         if (is_new) {
           my_new++;
           if (MODE != 1 && A.want_hist) {
+            if (A.newchunks) hcnt[nhx] |= 0x80000000u;   // collected below (the count was consumed above)
             if (mc < A.hist_base) my_before++;
             else {
               uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
@@ -516,6 +519,18 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (A.want_hist && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
   }
   SHK_STAMP(5);   // scan + statistics
+  if (MODE != 1 && A.want_hist && A.newchunks && !fatal) {
+    // first chunks of the region's new keys, compacted: k_chunk_hist turns them into the exact
+    // per-chunk histogram from which the host reads the chunk of a deNoise point
+    uint16_t *nc = A.newchunks + (size_t)r * SHK_HCAP;
+    uint32_t base = 0;
+    for (uint32_t h = tid; h < SHK_HCAP; h += SHK_WAVE) {
+      const bool f = hkey[h] != SHK_EMPTY && (hcnt[h] >> 31);
+      const unsigned long long m = __ballot(f);
+      if (f) nc[base + (uint32_t)__popcll(m & ((1ULL << tid) - 1))] = (uint16_t)(hkey[h] & (SHK_MAX_CHUNKS - 1));
+      base += (uint32_t)__popcll(m);
+    }
+  }
   if (MODE == 3) {
     // spill: 4 length bytes per lane, then the lanes' staged bytes back to back
     uint8_t *sp = A.spill + (size_t)r * SHK_SPILL_STRIDE;
@@ -814,6 +829,26 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
   }
   __syncthreads();
   shk_store_image<IMGB>(A, r, nregions, nimg, tid, nown, b0, q0, out_lo, out_hi, new_any, fout_rel);
+}
+
+// exact histogram of first chunks over all regions (input: newchunks + the regions' new-key counts)
+#define SHK_CHIST_REGIONS 2048   // regions per workgroup
+__global__ void k_chunk_hist(const uint16_t *newchunks, const uint32_t *summary, uint32_t nregions, unsigned long long *chist) {
+  __shared__ uint32_t lh[SHK_MAX_CHUNKS];
+  for (uint32_t i = threadIdx.x; i < SHK_MAX_CHUNKS; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const uint32_t lane = shk_lane(), wave = shk_wave(), nw = blockDim.x / SHK_WAVE;
+  const uint32_t r0 = blockIdx.x * SHK_CHIST_REGIONS;
+  for (uint32_t i = wave; i < SHK_CHIST_REGIONS; i += nw) {
+    const uint32_t r = r0 + i;
+    if (r >= nregions) break;
+    const uint32_t n = summary[(size_t)SHK_SUM_STRIDE * r + 2];
+    const uint16_t *nc = newchunks + (size_t)r * SHK_HCAP;
+    for (uint32_t j = lane; j < n && j < SHK_HCAP; j += SHK_WAVE) atomicAdd(&lh[nc[j]], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < SHK_MAX_CHUNKS; i += blockDim.x)
+    if (lh[i]) atomicAdd(&chist[i], (unsigned long long)lh[i]);
 }
 
 // statistics of a single-launch rebuild (MODE 2): sum the per-region records

@@ -69,6 +69,9 @@ struct shk_ctx {
   // what the spill records currently describe (a write pass may use them only for the same request)
   int spill_valid; const uint64_t *spill_words; uint32_t spill_lo, spill_hi; int spill_denoise, spill_big;
   uint64_t spill_nover;
+  uint16_t *d_newchunks;        // first chunks of new keys per region (exact deNoise point in one pass); null without deNoise rounds
+  unsigned long long *d_chist;  // [SHK_MAX_CHUNKS]
+  uint64_t *h_chist;            // pinned
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -222,6 +225,10 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (dmalloc(&c->d_lb_agg, (uint64_t)c->nregions + 2) || dmalloc(&c->d_lb_incl, (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
   c->single_ok = getenv("SHK_SINGLE") ? 1 : 0;
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
+  if (cfg->num_denoise && !getenv("SHK_COARSE_HIST")) {
+    if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
+    HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
+  }
   if (dmalloc(&c->d_spill, (uint64_t)c->nregions * SHK_SPILL_STRIDE) || dmalloc(&c->d_over_list, (uint64_t)c->nregions + 1)) return SHK_ERR_HIP;
   { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
     if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
@@ -257,7 +264,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
-  hipFree(c->d_spill); hipFree(c->d_over_list); hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
+  hipFree(c->d_spill); hipFree(c->d_over_list); if (c->d_newchunks) { hipFree(c->d_newchunks); hipFree(c->d_chist); hipHostFree(c->h_chist); } hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
   hipHostFree(c->h_pinned);
   hipStreamDestroy(c->stream);
   delete c;
@@ -372,6 +379,7 @@ struct MergeOut {
   uint64_t newd, added, removed, before;
   uint64_t hist[SHK_HIST_BINS];
   uint32_t err;
+  int have_chist;               // c->h_chist[chunk] = new keys first seen in that chunk (exact)
 };
 
 static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t hbase,
@@ -386,6 +394,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
   A->dbg = getenv("SHK_STAMPS") ? (unsigned long long *)(c->d_scalars + 16) : nullptr;
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
+  A->newchunks = nullptr;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -397,6 +406,9 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
   spill = spill && c->use_spill;
   c->spill_valid = 0;
+  const bool exact = want_hist == 2 && c->d_newchunks;
+  if (exact) A.newchunks = c->d_newchunks;
+  o->have_chist = 0;
   if (spill) { ProfScope ps(c, KP_MERGE_SPILL);
     launch_merge<3>(c, A); }
   else { ProfScope ps(c, KP_MERGE_SUM);
@@ -407,6 +419,13 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
     hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
     hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
                        c->xnslots, (uint32_t)(c->big_image ? SHK_IMG_BLOCKS_BIG * 64 : SHK_IMG_SLOTS), c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
+  if (exact) {
+    ProfScope ps(c, KP_MISC);
+    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+    hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
+                       c->d_newchunks, c->d_summary, c->nregions, c->d_chist);
+    HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
@@ -416,6 +435,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   o->err = *(uint32_t *)(c->h_pinned + 40);
   if (o->err) c->last_err_bits = o->err;
   if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  o->have_chist = exact ? 1 : 0;
   if (spill && !o->err) {
     c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = denoise;
     c->spill_big = c->big_image; c->spill_nover = c->h_pinned[4 + SHK_HIST_BINS];
@@ -464,6 +484,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemsetAsync(c->d_lb_incl, 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   c->spill_valid = 0;
+  o->have_chist = 0;
   { ProfScope ps(c, KP_MERGE_SINGLE);
     launch_merge<2>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
@@ -573,7 +594,7 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
       uint32_t span = hi - lo + 1;
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
-      const int wh = (likely || (possible && c->use_spill)) ? 1 : 0;
+      const int wh = (likely || (possible && c->use_spill)) ? 2 : 0;
       rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, wh, 1);
       if (rc) return rc;
       if (wh && !(o.err & ~soft)) have_hist = true;
@@ -592,10 +613,20 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
       // only now is the per-chunk histogram of first occurrences needed
       uint32_t base = lo;
       if (!have_hist) {
-        rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, 1);
+        rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, 2);
         if (rc) return rc;
         if (o.err & ~soft) return map_err_bits(o.err & ~soft);
       }
+      if (o.have_chist) {
+        // exact: first chunk at which the running distinct count reaches the trigger
+        uint64_t run = c->ndistinct;
+        uint32_t ch = lo;
+        for (; ch < hi; ch++) {
+          run += c->h_chist[ch];
+          if (run >= c->cfg.ndistinct_for_denoise) break;
+        }
+        hi = ch;
+      } else
       for (;;) {
         uint32_t bin = 0;
         uint64_t run = c->ndistinct + o.before;
