@@ -137,6 +137,12 @@ int shk_stage_commit(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, const s
 int shk_stage_try(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                   int want_hist, shk_summary *out);
 int shk_stage_accept(shk_ctx *ctx, const shk_summary *s);
+/* want_hist = 2 in shk_stage_summary / shk_stage_try additionally records the first chunk of every
+ * new key; this call returns the exact histogram of that last pass: out[i] = new keys first seen in
+ * chunk i, for i < n (n <= chunk_hi + 1 of the pass). With it the ranks find the chunk of a deNoise
+ * point in one pass instead of refining the 32-bin histogram. SHK_ERR_ARG when the last pass has none
+ * (contexts created with num_denoise = 0 never have one). */
+int shk_stage_chunk_hist(shk_ctx *ctx, uint64_t *out, uint32_t n);
 
 /* One deNoise round now (the reference's --endDeNoise round; does not use up num_denoise). */
 int shk_denoise(shk_ctx *ctx, uint64_t *removed);

@@ -72,6 +72,7 @@ struct shk_ctx {
   uint16_t *d_newchunks;        // first chunks of new keys per region (exact deNoise point in one pass); null without deNoise rounds
   unsigned long long *d_chist;  // [SHK_MAX_CHUNKS]
   uint64_t *h_chist;            // pinned
+  uint32_t chist_n;             // entries of h_chist valid from the last summary (0 = none)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -436,6 +437,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   if (o->err) c->last_err_bits = o->err;
   if (o->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
   o->have_chist = exact ? 1 : 0;
+  c->chist_n = exact ? hi + 1 : 0;
   if (spill && !o->err) {
     c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = denoise;
     c->spill_big = c->big_image; c->spill_nover = c->h_pinned[4 + SHK_HIST_BINS];
@@ -485,6 +487,7 @@ static int merge_single(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   c->spill_valid = 0;
   o->have_chist = 0;
+  c->chist_n = 0;
   { ProfScope ps(c, KP_MERGE_SINGLE);
     launch_merge<2>(c, A); }
   { ProfScope ps(c, KP_REGION_SCAN);
@@ -887,6 +890,12 @@ extern "C" int shk_stage_accept(shk_ctx *c, const shk_summary *s) {
   }
   c->ndistinct += s->new_distinct; c->nelts += s->added;
   return finish(c, SHK_OK);
+}
+
+extern "C" int shk_stage_chunk_hist(shk_ctx *c, uint64_t *out, uint32_t n) {
+  if (!c || !out || !c->chist_n || n > c->chist_n) return SHK_ERR_ARG;
+  memcpy(out, c->h_chist, (size_t)n * sizeof(uint64_t));
+  return SHK_OK;
 }
 
 extern "C" int shk_denoise(shk_ctx *c, uint64_t *removed) {

@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_denoise",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
            "shk_last_error_bits"]
@@ -89,6 +89,7 @@ def load(path=None):
     L.shk_stage_commit.argtypes = [vp, u32, u32, C.POINTER(Summary)]
     L.shk_stage_try.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
     L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
+    L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
     L.shk_denoise.argtypes = [vp, pu64]
     L.shk_stats.argtypes = [vp, C.POINTER(Totals)]
     L.shk_header.argtypes = [vp, C.c_char_p]
@@ -197,13 +198,20 @@ class Context:
 
     def stage_summary(self, lo, hi, hist_base=0, hist_shift=0, want_hist=False):
         s = Summary()
-        self._chk(self.L.shk_stage_summary(self.h, lo, hi, hist_base, hist_shift, 1 if want_hist else 0, C.byref(s)))
+        self._chk(self.L.shk_stage_summary(self.h, lo, hi, hist_base, hist_shift, int(want_hist), C.byref(s)))
         return s
 
     def stage_try(self, lo, hi, hist_base=0, hist_shift=0, want_hist=False):
         s = Summary()
-        self._chk(self.L.shk_stage_try(self.h, lo, hi, hist_base, hist_shift, 1 if want_hist else 0, C.byref(s)))
+        self._chk(self.L.shk_stage_try(self.h, lo, hi, hist_base, hist_shift, int(want_hist), C.byref(s)))
         return s
+
+    def stage_chunk_hist(self, n):
+        """exact per-chunk histogram of the last pass run with want_hist=2, or None when it has none"""
+        out = (C.c_uint64 * max(n, 1))()
+        if self.L.shk_stage_chunk_hist(self.h, out, n) != 0:
+            return None
+        return [out[i] for i in range(n)]
 
     def stage_accept(self, summary):
         self._chk(self.L.shk_stage_accept(self.h, C.byref(summary)))

@@ -37,6 +37,23 @@ def _summary(ctx, st, lo, hi, base, shift, want_hist, single=False):
     return red[0], red[1], red[2:], flags[0], flags[1], flags[2], s
 
 
+def _exact_point(ctx, st, lo, hi):
+    """global chunk at which the filter-wide distinct count reaches the trigger, from the exact
+    per-chunk histograms of the pass just run with want_hist=2 (None when a rank has none)"""
+    h = ctx.stage_chunk_hist(hi + 1)
+    ok = _allreduce([0 if h is None else 1], st.device, dist.ReduceOp.MIN)[0]
+    if not ok:
+        return None
+    t = torch.tensor(h[lo:hi + 1], dtype=torch.int64, device=st.device)
+    dist.all_reduce(t)
+    run = st.ndistinct
+    for i, v in enumerate(t.tolist()):
+        run += v
+        if run >= st.trigger:
+            return lo + i
+    return hi
+
+
 def sharded_count(ctx, st, nchunks):
     """insert the staged words of global chunks [0, nchunks); returns dict(kmers, new_distinct, removed, rounds)"""
     out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
@@ -44,12 +61,14 @@ def sharded_count(ctx, st, nchunks):
     while lo < nchunks:
         hi = nchunks - 1
         watch = st.rounds_left > 0
-        # common case: one launch per rank does statistics and table; accepted when no rank saw an
-        # error and the whole filter stays below the trigger
-        newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False, single=True)
+        # common case: one try per rank does statistics (and, in the single-launch scheme, the table);
+        # accepted when no rank saw an error and the whole filter stays below the trigger. While rounds
+        # are left the try also records first chunks, so a deNoise point is located without more passes.
+        newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, 2 if watch else 0, single=True)
         if hard:
             ctx.error_for_bits(hard)
-        if not (hfull or soft) and not (watch and st.ndistinct + newd >= st.trigger):
+        crosses = watch and st.ndistinct + newd >= st.trigger
+        if not (hfull or soft) and not crosses:
             ctx.stage_accept(loc)
             added = _allreduce([loc.added], st.device)[0]
             st.ndistinct += newd
@@ -58,58 +77,65 @@ def sharded_count(ctx, st, nchunks):
             out["new_distinct"] += newd
             lo = hi + 1
             continue
-        while True:
-            span = hi - lo + 1
-            shift = 0
-            while ((span + (1 << shift) - 1) >> shift) > HIST_BINS:
-                shift += 1
-            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, False)
-            if hard:
-                ctx.error_for_bits(hard)
-            if hfull:
-                if hi == lo:
-                    ctx.error_for_bits(HASH_FULL_BIT)
-                hi = lo + (hi - lo) // 2
-                continue
-            break
-        fire = False
-        if watch and st.ndistinct + newd >= st.trigger:
-            base = lo
-            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, True)
-            if hard:
-                ctx.error_for_bits(hard)
+        point = _exact_point(ctx, st, lo, hi) if (crosses and not hfull) else None
+        if point is None:
             while True:
-                run = st.ndistinct + before
-                b = 0
-                while b < HIST_BINS:
-                    if run + hist[b] >= st.trigger:
-                        break
-                    run += hist[b]
-                    b += 1
-                b = min(b, HIST_BINS - 1)
-                b_lo = base + (b << shift)
-                b_hi = min(b_lo + (1 << shift) - 1, hi)
-                if shift == 0:
-                    hi = b_lo
-                    break
-                span2 = b_hi - b_lo + 1
+                span = hi - lo + 1
                 shift = 0
-                while ((span2 + (1 << shift) - 1) >> shift) > HIST_BINS:
+                while ((span + (1 << shift) - 1) >> shift) > HIST_BINS:
                     shift += 1
-                base = b_lo
-                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, b_hi, base, shift, True)
+                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, 2 if watch else 0)
                 if hard:
                     ctx.error_for_bits(hard)
+                if hfull:
+                    if hi == lo:
+                        ctx.error_for_bits(HASH_FULL_BIT)
+                    hi = lo + (hi - lo) // 2
+                    continue
+                break
+            crosses = watch and st.ndistinct + newd >= st.trigger
+            if crosses:
+                point = _exact_point(ctx, st, lo, hi)
+        fire = False
+        accepted = False
+        if crosses:
+            if point is not None:
+                hi = point
+            else:
+                # 32-bin refinement (contexts without the exact histogram)
+                base = lo
+                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, True)
+                if hard:
+                    ctx.error_for_bits(hard)
+                while True:
+                    run = st.ndistinct + before
+                    b = 0
+                    while b < HIST_BINS:
+                        if run + hist[b] >= st.trigger:
+                            break
+                        run += hist[b]
+                        b += 1
+                    b = min(b, HIST_BINS - 1)
+                    b_lo = base + (b << shift)
+                    b_hi = min(b_lo + (1 << shift) - 1, hi)
+                    if shift == 0:
+                        hi = b_lo
+                        break
+                    span2 = b_hi - b_lo + 1
+                    shift = 0
+                    while ((span2 + (1 << shift) - 1) >> shift) > HIST_BINS:
+                        shift += 1
+                    base = b_lo
+                    newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, b_hi, base, shift, True)
+                    if hard:
+                        ctx.error_for_bits(hard)
             fire = True
             newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False, single=True)
             if not (hard or hfull or soft):
                 ctx.stage_accept(loc)
                 accepted = True
             else:
-                accepted = False
                 newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False)
-        else:
-            accepted = False
         if hard or hfull or soft:
             ctx.error_for_bits(hard | hfull | soft)
         if not accepted:
