@@ -452,8 +452,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         if (is_new) {
           my_new++;
           if (MODE != 1 && A.want_hist) {
-            if (A.newchunks) hcnt[nhx] |= 0x80000000u;   // collected below (the count was consumed above)
-            if (mc < A.hist_base) my_before++;
+            // exact mode: the key is only flagged here and its first chunk collected below (the count
+            // was consumed above); the coarse histogram would cost one global atomic per bin and region
+            if (A.newchunks) hcnt[nhx] |= 0x80000000u;
+            else if (mc < A.hist_base) my_before++;
             else {
               uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
               atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
@@ -516,7 +518,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       if (tot.a > 0xFFFF) atomicOr(A.err, SHK_E_RUN_TOO_LONG);
       if (s_fail) atomicOr(A.err, s_fail);
     }
-    if (A.want_hist && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
+    if (A.want_hist && !A.newchunks && tid < SHK_HIST_BINS && lhist[tid]) atomicAdd(&A.hist[tid], (unsigned long long)lhist[tid]);
   }
   SHK_STAMP(5);   // scan + statistics
   if (MODE != 1 && A.want_hist && A.newchunks && !fatal) {
