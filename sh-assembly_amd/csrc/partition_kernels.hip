@@ -95,23 +95,36 @@ __global__ void k_rp_tile_first(const uint64_t *bucket_base, uint32_t nbuckets, 
   tfb[w] = lo;
 }
 
+// Histogram of the next digit. One workgroup takes `wtiles` consecutive windows, so that the global
+// counters of a (bucket, digit) see one atomic per workgroup and bucket, not one per window
+// (at the first level every window would hit the same P addresses).
 __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint64_t *bucket_base,
-                          const uint32_t *tfb, ShkRpLevel lv, uint64_t *hist) {
+                          const uint32_t *tfb, ShkRpLevel lv, uint64_t *hist, uint32_t wtiles) {
   __shared__ uint32_t lh[SHK_RP_MAXP];
   const uint64_t n = *n_p;
-  const uint64_t wstart = (uint64_t)blockIdx.x * SHK_RP_TILE;
+  const uint64_t wstart = (uint64_t)blockIdx.x * wtiles * SHK_RP_TILE;
   if (wstart >= n) return;
-  const uint64_t wend = wstart + SHK_RP_TILE < n ? wstart + SHK_RP_TILE : n;
+  const uint64_t wend = wstart + (uint64_t)wtiles * SHK_RP_TILE < n ? wstart + (uint64_t)wtiles * SHK_RP_TILE : n;
   const uint32_t P = 1u << lv.bits;
-  for (uint32_t b = tfb[blockIdx.x]; b < lv.nbuckets && bucket_base[b] < wend; b++) {
+  for (uint32_t b = tfb[(uint64_t)blockIdx.x * wtiles]; b < lv.nbuckets && bucket_base[b] < wend; b++) {
     const uint64_t lo = bucket_base[b] > wstart ? bucket_base[b] : wstart;
     const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
     if (hi <= lo) continue;
     for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
     __syncthreads();
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      uint32_t d = (shk_word_region(words[i], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-      atomicAdd(&lh[d], 1u);
+    // four loads in flight per thread
+    for (uint64_t i0 = lo; i0 < hi; i0 += 4ull * blockDim.x) {
+      uint64_t w[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
+        w[u] = i < hi ? words[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
+        if (i < hi) atomicAdd(&lh[(shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1)], 1u);
+      }
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
@@ -120,10 +133,17 @@ __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint
   }
 }
 
-// cursor[b*P+d] starts at the scanned base of (b,d) and is advanced by reservations
-__global__ void k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p, const uint64_t *bucket_base,
-                             const uint32_t *tfb, ShkRpLevel lv, uint64_t *cursor) {
-  __shared__ uint32_t lh[SHK_RP_MAXP];      // counts, then running rank
+// cursor[b*P+d] starts at the scanned base of (b,d) and is advanced by reservations.
+// One window of SHK_RP_TILE keys per workgroup of SHK_RP_THREADS threads: the keys stay in
+// registers; ONE LDS atomic per key yields both the digit count and the key's rank inside
+// its digit (the order of keys inside a bucket is free: the rebuild folds them into a hash);
+// after the scan the keys are staged digit by digit in LDS and leave as contiguous runs.
+#define SHK_RP_THREADS 512
+#define SHK_RP_KPT (SHK_RP_TILE / SHK_RP_THREADS)
+__global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
+                                                               const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
+                                                               uint64_t *cursor) {
+  __shared__ uint32_t lh[SHK_RP_MAXP];      // digit counts (= next rank while counting)
   __shared__ uint32_t lbase[SHK_RP_MAXP];   // local exclusive base of each digit
   __shared__ uint64_t gbase[SHK_RP_MAXP];   // reserved global base of each digit
   __shared__ uint64_t stage[SHK_RP_TILE];
@@ -138,16 +158,28 @@ __global__ void k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *
     const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
     if (hi <= lo) continue;
     const uint32_t cnt = (uint32_t)(hi - lo);
-    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-      uint32_t d = (shk_word_region(in[lo + i], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-      atomicAdd(&lh[d], 1u);
+    for (uint32_t d = threadIdx.x; d < P; d += SHK_RP_THREADS) lh[d] = 0;
+    uint64_t w[SHK_RP_KPT];
+#pragma unroll
+    for (int u = 0; u < SHK_RP_KPT; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+      w[u] = i < cnt ? in[lo + i] : 0;
     }
     __syncthreads();
-    // exclusive scan of the digit counts (P <= 1024, blockDim may be smaller)
+    uint32_t dr[SHK_RP_KPT];               // digit << 16 | rank inside the digit (rank < SHK_RP_TILE)
+#pragma unroll
+    for (int u = 0; u < SHK_RP_KPT; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+      dr[u] = 0;
+      if (i < cnt) {
+        const uint32_t d = (shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+        dr[u] = (d << 16) | atomicAdd(&lh[d], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the digit counts (P <= 1024)
     uint32_t carry = 0;
-    for (uint32_t d0 = 0; d0 < P; d0 += blockDim.x) {
+    for (uint32_t d0 = 0; d0 < P; d0 += SHK_RP_THREADS) {
       uint32_t d = d0 + threadIdx.x;
       uint32_t v = d < P ? lh[d] : 0, tot;
       uint32_t ex = shk_block_exscan(v, &tot, scratch);
@@ -158,19 +190,16 @@ __global__ void k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *
       carry += tot;
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-      uint64_t w = in[lo + i];
-      uint32_t d = (shk_word_region(w, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-      uint32_t rank = atomicAdd(&lh[d], 1u);
-      stage[lbase[d] + rank] = w;
+#pragma unroll
+    for (int u = 0; u < SHK_RP_KPT; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+      if (i < cnt) stage[lbase[dr[u] >> 16] + (dr[u] & 0xFFFFu)] = w[u];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-      uint64_t w = stage[i];
-      uint32_t d = (shk_word_region(w, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-      out[gbase[d] + (i - lbase[d])] = w;
+    for (uint32_t i = threadIdx.x; i < cnt; i += SHK_RP_THREADS) {
+      uint64_t x = stage[i];
+      uint32_t d = (shk_word_region(x, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+      out[gbase[d] + (i - lbase[d])] = x;
     }
     __syncthreads();
   }

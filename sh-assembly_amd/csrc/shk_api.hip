@@ -352,11 +352,12 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
       hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
       HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
     { ProfScope ps(c, KP_RP_HIST);
-      hipLaunchKernelGGL(k_rp_hist, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[cur], n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l]); }
+      const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
+      hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, c->d_words[cur], n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
     if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
     HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
     { ProfScope ps(c, KP_RP_SCATTER);
-      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[cur], c->d_words[cur ^ 1], n_p,
+      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[cur], c->d_words[cur ^ 1], n_p,
                          c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor); }
     cur ^= 1;
   }
@@ -797,7 +798,8 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
     hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[0], 1u, n_p, c->d_tfb);
     HIPCHK(hipMemsetAsync(hist, 0, nshards * 8, c->stream)); }
   { ProfScope ps(c, KP_RP_HIST);
-    hipLaunchKernelGGL(k_rp_hist, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[0], n_p, c->d_base[0], c->d_tfb, lv, hist); }
+    const uint32_t wt = nwin / 4096 + 1;
+    hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, c->d_words[0], n_p, c->d_base[0], c->d_tfb, lv, hist, wt); }
   HIPCHK(hipMemcpyAsync(c->h_pinned + 16, hist, nshards * 8 > 16 * 8 ? 16 * 8 : nshards * 8, hipMemcpyDeviceToHost, c->stream));
   std::vector<uint64_t> hh(nshards);
   HIPCHK(hipMemcpyAsync(hh.data(), hist, nshards * 8, hipMemcpyDeviceToHost, c->stream));
@@ -807,7 +809,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   HIPCHK(hipMemcpyAsync(cursor, bb.data(), nshards * 8, hipMemcpyHostToDevice, c->stream));
   (void)base;
   { ProfScope ps(c, KP_RP_SCATTER);
-    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(c->threads), 0, c->stream, c->d_words[0], c->d_words[1], n_p,
+    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], c->d_words[1], n_p,
                        c->d_base[0], c->d_tfb, lv, cursor); }
   HIPCHK(hipGetLastError());
   *d_out = c->d_words[1];
