@@ -437,7 +437,14 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
             prot = (oimg[tb] >> (opos & 7)) & 1;
           }
-          if (orem == nrem) { total += hcnt[nh]; adv = true; }
+          // a deNoise round drops the OLD singleton first; words of this pass (chunks behind the
+          // deNoise point) then count as if the key had never been seen (qf_clean_singleton, then inserts)
+          const bool drop = A.denoise && ocnt < 2 && !prot;
+          if (drop) { my_removed++; total = 0; }
+          if (orem == nrem) {
+            total += hcnt[nh]; adv = true;
+            if (drop) { is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); nhx = nh; }
+          }
           opos += on;
           if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt); else ohas = false;
         } else {
@@ -448,7 +455,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           nrem = 256;
           if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
         }
-        if (A.denoise && total < 2 && !prot) { my_removed++; continue; }
+        if (total == 0) continue;
         if (is_new) {
           my_new++;
           if (MODE != 1 && A.want_hist) {
@@ -706,6 +713,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
           prot = (oimg[tb] >> (opos & 7)) & 1;
         }
+        if (A.denoise && ocnt < 2 && !prot) total = 0;
         if (orem == nrem) { total += hcnt[nh]; adv = true; }
         opos += on;
         if (opos <= oend) on = shk_img_dec(oimg, opos, oend, &orem, &ocnt); else ohas = false;
@@ -717,7 +725,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         nrem = 256;
         if (ni < ne) { nh = nidx[ni]; nrem = (hkey[nh] >> SHK_CHUNK_BITS) & 0xff; }
       }
-      if (A.denoise && total < 2 && !prot) continue;
+      if (total == 0) continue;
       const unsigned n = shk_enc_write(enc, rem, total);
       for (unsigned i = 0; i < n; i++) nimg[shk_img_slot_off(wp + i)] = enc[i];
       wp += n;

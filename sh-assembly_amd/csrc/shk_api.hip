@@ -535,6 +535,32 @@ static int denoise_round_once(shk_ctx *c, uint64_t *removed) {
   return SHK_OK;
 }
 
+// deNoise round fused with the insertion of the chunks behind the deNoise point (one pass over the
+// table instead of two). Not taken (*done = false) when the pass reports anything unusual or the
+// trigger would be reached again inside [lo, hi]: the caller then runs the plain round.
+static int denoise_with_rest(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, shk_batch_stats *st, bool *done) {
+  *done = false;
+  if (!c->use_spill) return SHK_OK;
+  uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
+  { ProfScope ps(c, KP_MARKS);
+    hipLaunchKernelGGL(k_denoise_marks, dim3(1), dim3(64), 0, c->stream, c->tab[c->cur], c->nslots, c->xnslots, c->nblocks,
+                       ml, (unsigned long long *)(c->d_scalars + 3)); }
+  MergeOut o;
+  int rc = merge_summary(c, words, lo, hi, lo, 0, 1, &o, 0, 1);
+  if (rc) return rc;
+  if (o.err) return SHK_OK;
+  if (c->rounds_left > 0 && c->ndistinct - o.removed + o.newd >= c->cfg.ndistinct_for_denoise) return SHK_OK;
+  rc = merge_write(c, words, lo, hi, 1);
+  if (rc) return rc;
+  c->nelts = c->nelts - o.removed + o.added;        // CQF_mt.h:1037-1038, then the inserts
+  c->ndistinct = c->ndistinct - o.removed + o.newd;
+  st->removed += o.removed; st->denoise_rounds++;
+  st->kmers += o.added; st->new_distinct += o.newd; st->chunks += hi - lo + 1;
+  c->big_image = 0;
+  *done = true;
+  return SHK_OK;
+}
+
 static int denoise_round(shk_ctx *c, uint64_t *removed) {
   int rc = denoise_round_once(c, removed);
   if (rc == SHK_ERR_REGION && !c->big_image && (c->last_err_bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT))) {
@@ -686,6 +712,12 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
       uint64_t removed = 0;
       c->rounds_left--;
       c->rounds_done++;
+      if (hi + 1 < nchunks) {
+        bool done = false;
+        rc = denoise_with_rest(c, words, hi + 1, nchunks - 1, st, &done);
+        if (rc) return rc;
+        if (done) { lo = nchunks; continue; }
+      }
       rc = denoise_round(c, &removed);
       if (rc) return rc;
       st->removed += removed;
