@@ -62,31 +62,50 @@ __device__ __forceinline__ uint4 shk_unit_flags(const uint8_t *text, uint64_t a0
 }
 
 // ---------------------------------------------------------------- lines per chunk
+// A chunk (8 MiB) is cut into SHK_PARSE_SEGS segments of whole 16-byte units; one workgroup per
+// segment, so a batch of a few hundred chunks fills the device.
+#define SHK_PARSE_SEGS 16
+__device__ __forceinline__ void shk_segment_units(uint64_t nunits, unsigned seg, uint64_t *u0, uint64_t *u1) {
+  const uint64_t per = (nunits + SHK_PARSE_SEGS - 1) / SHK_PARSE_SEGS;
+  *u0 = per * seg < nunits ? per * seg : nunits;
+  *u1 = *u0 + per < nunits ? *u0 + per : nunits;
+}
+
 __global__ void k_count_lines(const uint8_t *text, const uint64_t *chunk_off, const uint64_t *chunk_len,
-                              uint64_t *nlines) {
+                              uint64_t *nlines_seg) {
   __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
-  const unsigned c = blockIdx.x;
+  const unsigned c = blockIdx.x / SHK_PARSE_SEGS, seg = blockIdx.x % SHK_PARSE_SEGS;
   const uint64_t off = chunk_off[c], end = off + chunk_len[c];
   const uint64_t a0 = off & ~15ULL;
   const uint64_t nunits = (end - a0 + 15) / 16;
+  uint64_t u0, u1;
+  shk_segment_units(nunits, seg, &u0, &u1);
   uint64_t cnt = 0;
-  for (uint64_t u = threadIdx.x; u < nunits; u += blockDim.x) {
+  for (uint64_t u = u0 + threadIdx.x; u < u1; u += blockDim.x) {
     uint4 f = shk_unit_flags(text, a0, u, off, end);
     cnt += __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);
   }
   uint64_t tot = shk_block_sum64(cnt, scratch);
-  if (threadIdx.x == 0) nlines[c] = tot;
+  if (threadIdx.x == 0) nlines_seg[blockIdx.x] = tot;
 }
 
-// reads per chunk = #newlines with index 1 mod 4 = (nl+2)/4; first read index per chunk
-__global__ void k_scan_chunks(const uint64_t *nlines, unsigned nchunks, uint64_t *reads_base, uint64_t *nreads_total) {
+// reads per chunk = #newlines with index 1 mod 4 = (nl+2)/4; first read index per chunk;
+// nlines_seg[] is turned into the first line index of every segment inside its chunk
+__global__ void k_scan_chunks(uint64_t *nlines_seg, unsigned nchunks, uint64_t *reads_base, uint64_t *nreads_total) {
   __shared__ uint64_t scratch[SHK_MAX_WAVES + 1];
   __shared__ uint64_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (unsigned base = 0; base < nchunks; base += blockDim.x) {
     unsigned c = base + threadIdx.x;
-    uint64_t v = c < nchunks ? (nlines[c] + 2) / 4 : 0;
+    uint64_t nl = 0;
+    if (c < nchunks)
+      for (unsigned sg = 0; sg < SHK_PARSE_SEGS; sg++) {
+        const uint64_t v = nlines_seg[(uint64_t)c * SHK_PARSE_SEGS + sg];
+        nlines_seg[(uint64_t)c * SHK_PARSE_SEGS + sg] = nl;
+        nl += v;
+      }
+    uint64_t v = c < nchunks ? (nl + 2) / 4 : 0;
     uint64_t tot;
     uint64_t ex = shk_block_exscan64(v, &tot, scratch);
     uint64_t carry = carry_s;
@@ -105,20 +124,22 @@ __global__ void k_scan_chunks(const uint64_t *nlines, unsigned nchunks, uint64_t
 // Line l (0-based, by newline count from the chunk start) is a header when l%4==0 and
 // the read when l%4==1 -- the same strict 4-line walk as CQF_mt.h:616-726.
 __global__ void k_emit_reads(const uint8_t *text, const uint64_t *chunk_off, const uint64_t *chunk_len,
-                             const uint64_t *reads_base, uint64_t *rd_start, uint64_t *rd_end) {
+                             const uint64_t *reads_base, const uint64_t *line_base_seg, uint64_t *rd_start, uint64_t *rd_end) {
   __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
   __shared__ uint64_t line_carry;
-  const unsigned c = blockIdx.x;
+  const unsigned c = blockIdx.x / SHK_PARSE_SEGS, seg = blockIdx.x % SHK_PARSE_SEGS;
   const uint64_t off = chunk_off[c], end = off + chunk_len[c];
   const uint64_t a0 = off & ~15ULL;
   const uint64_t nunits = (end - a0 + 15) / 16;
+  uint64_t u0, u1;
+  shk_segment_units(nunits, seg, &u0, &u1);
   const uint64_t rbase = reads_base[c], nreads = reads_base[c + 1] - rbase;
-  if (threadIdx.x == 0) line_carry = 0;
+  if (threadIdx.x == 0) line_carry = line_base_seg[blockIdx.x];
   __syncthreads();
-  for (uint64_t ub = 0; ub < nunits; ub += blockDim.x) {
+  for (uint64_t ub = u0; ub < u1; ub += blockDim.x) {
     uint64_t u = ub + threadIdx.x;
     uint4 f = make_uint4(0, 0, 0, 0);
-    if (u < nunits) f = shk_unit_flags(text, a0, u, off, end);
+    if (u < u1) f = shk_unit_flags(text, a0, u, off, end);
     uint32_t n = __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);
     uint32_t tot;
     uint32_t ex = shk_block_exscan(n, &tot, scratch);

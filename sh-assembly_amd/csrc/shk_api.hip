@@ -199,7 +199,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
     if (dmalloc(&c->d_words[i], capk + 1)) return SHK_ERR_HIP;
   }
   if (dmalloc(&c->d_text, cfg->max_batch_bytes + 64)) return SHK_ERR_HIP;
-  if (dmalloc(&c->d_chunk_off, maxch) || dmalloc(&c->d_chunk_len, maxch) || dmalloc(&c->d_nlines, maxch) ||
+  if (dmalloc(&c->d_chunk_off, maxch) || dmalloc(&c->d_chunk_len, maxch) || dmalloc(&c->d_nlines, (uint64_t)maxch * SHK_PARSE_SEGS) ||
       dmalloc(&c->d_reads_base, maxch + 1)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_rd_start, c->max_reads + 1) || dmalloc(&c->d_rd_end, c->max_reads + 1) ||
       dmalloc(&c->d_nkeys, c->max_reads + 1) || dmalloc(&c->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
@@ -310,7 +310,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   HIPCHK(hipMemcpyAsync(c->d_chunk_off, chunk_off, nchunks * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_chunk_len, chunk_len, nchunks * 8, hipMemcpyHostToDevice, c->stream));
   { ProfScope ps(c, KP_COUNT_LINES);
-    hipLaunchKernelGGL(k_count_lines, dim3(nchunks), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len, c->d_nlines); }
+    hipLaunchKernelGGL(k_count_lines, dim3(nchunks * SHK_PARSE_SEGS), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len, c->d_nlines); }
   { ProfScope ps(c, KP_SCAN_CHUNKS);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(c->threads), 0, c->stream, c->d_nlines, nchunks, c->d_reads_base, c->d_scalars + 0); }
   // the read arrays are sized by max_reads: the count is checked on the host below
@@ -319,8 +319,8 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   const uint64_t nreads = c->h_pinned[41];
   if (nreads > c->max_reads) return SHK_ERR_BATCH;
   { ProfScope ps(c, KP_EMIT_READS);
-    hipLaunchKernelGGL(k_emit_reads, dim3(nchunks), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len,
-                       c->d_reads_base, c->d_rd_start, c->d_rd_end); }
+    hipLaunchKernelGGL(k_emit_reads, dim3(nchunks * SHK_PARSE_SEGS), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len,
+                       c->d_reads_base, c->d_nlines, c->d_rd_start, c->d_rd_end); }
   uint32_t groups = c->hash_groups;
   { uint64_t need = nreads / (c->threads / SHK_WAVE) + 1; if (need < groups) groups = (uint32_t)need; }
   { ProfScope ps(c, KP_COUNT_KEYS);
