@@ -214,13 +214,13 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ uint16_t rstart[SHK_REGION];
   __shared__ __attribute__((aligned(16))) uint8_t oimg[IMG_BYTES + 16];
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
-  __shared__ uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_PER_LANE];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_PER_LANE];
   __shared__ uint64_t oocc[SHK_REGION_BLOCKS];
   __shared__ uint64_t orunw[IMG_BLOCKS];
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
   __shared__ uint32_t orrank[IMG_BLOCKS + 1];
   __shared__ uint32_t lhist[SHK_HIST_BINS];
-  __shared__ uint32_t s_fail, s_added;
+  __shared__ uint32_t s_fail, s_added, s_nlist;
 
   unsigned long long t_prev = A.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned tid = threadIdx.x;
@@ -241,7 +241,9 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const uint32_t ohi = old_any ? (uint32_t)((fa1 - q0) > 0xFFFFFFF ? 0xFFFFFFF : (fa1 - q0)) : olo;
   uint32_t nblk_old = old_any ? (ohi + 63) / 64 : 0;
   if (nblk_old < nown) nblk_old = nown;
-  if (tid == 0) { s_fail = 0; s_added = 0; }
+  if (tid == 0) { s_fail = 0; s_added = 0; s_nlist = 0; }
+  // hash slots in use, in order of first insertion (lives in `stage`, which is idle until the merge pass)
+  uint16_t *slist = reinterpret_cast<uint16_t *>(stage);
   bool fatal = false;
   if (nblk_old > IMG_BLOCKS || ohi > IMG_SLOTS) {
     if (tid == 0) atomicOr(A.err, SHK_E_OLD_EXTENT);
@@ -268,49 +270,74 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
 
   SHK_STAMP(0);   // staging + init
   // ---- fold this region's new keys into the LDS hash
+  // The kernel is bound by scalar-ALU issue (divergent branches cost s_*exec instructions for the whole
+  // wave), so the probe loop is written branch-free: every lane executes every LDS operation, with
+  // operands that make it a no-op for lanes that have nothing (more) to insert -- a compare value no
+  // slot can hold, min with ~0, add 0. Four words per lane probe together; the loop condition is wave-uniform.
   uint32_t my_added = 0;
   if (A.words && !fatal && !(A.ablate & 1)) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
     const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
-    // four key words per lane are in flight before any of them is folded in: the loop is
-    // otherwise a chain of dependent HBM round trips
-    for (uint64_t i0 = kb; i0 < ke; i0 += 4 * ngrp) {
+    const unsigned lane = shk_lane();
+    const bool wh = A.want_hist != 0;
+    bool corrupt = false, hfull = false;
+    const uint32_t nw = (uint32_t)(ke - kb);   // a region's share of one batch is far below 2^32 words
+    const uint64_t *wp = A.words + kb;
+    for (uint32_t i0 = 0; i0 < nw; i0 += 4 * ngrp) {
       uint64_t wv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const uint64_t i = i0 + (uint64_t)u * ngrp + tid;
-        wv[u] = i < ke ? A.words[i] : ~0ULL;
+        const uint32_t i = i0 + (uint32_t)u * ngrp + tid;
+        wv[u] = i < nw ? wp[i] : ~0ULL;
       }
+      uint32_t h[4], want[4], chk[4];
+      bool pend[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint64_t w = wv[u];
-        if (i0 + (uint64_t)u * ngrp + tid >= ke) continue;
-        if (A.ablate & 256) { my_added += (uint32_t)(w & 1); continue; }   // diagnostics: loads only
+        const bool in = i0 + (uint32_t)u * ngrp + tid < nw;
         const uint32_t chunk = (uint32_t)(w >> A.hb);
-        if (chunk < A.chunk_lo || chunk > A.chunk_hi) continue;
         const uint64_t key = w & kmask;
         const uint32_t ql = (uint32_t)((key >> 8) - A.q_lo - q0);
-        if (ql >= nq) { atomicOr(A.err, SHK_E_CORRUPT); continue; }
-        const uint32_t tag = (ql << 8) | (uint32_t)(key & 0xff);
-        const uint32_t want = tag << SHK_CHUNK_BITS;
-        uint32_t h = (tag * 2654435761u) >> (32 - SHK_HCAP_LOG2);
-        if (A.ablate & 2048) { my_added += h & 1; continue; }
-        if (A.ablate & 1024) { atomicAdd(&hcnt[h], 1u); my_added++; continue; }
-        bool placed = false;
-        for (uint32_t probe = 0; probe < SHK_HCAP; probe++) {
-          uint32_t cur = hkey[h];
-          if (cur == SHK_EMPTY) {
-            uint32_t prev = atomicCAS(&hkey[h], SHK_EMPTY, want | (SHK_MAX_CHUNKS - 1));
-            if (prev == SHK_EMPTY || (prev >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
-          } else if ((cur >> SHK_CHUNK_BITS) == tag) { placed = true; break; }
-          h = (h + 1) & (SHK_HCAP - 1);
+        const bool inr = in && chunk >= A.chunk_lo && chunk <= A.chunk_hi;
+        corrupt |= inr && ql >= nq;
+        pend[u] = inr && ql < nq;
+        const uint32_t tag = ((ql << 8) | (uint32_t)(key & 0xff)) & 0xFFFFu;
+        want[u] = tag << SHK_CHUNK_BITS;
+        chk[u] = chunk & (SHK_MAX_CHUNKS - 1);
+        h[u] = (__umul24(tag, 40503u) & 0xFFFFu) >> (16 - SHK_HCAP_LOG2);   // 16-bit multiplicative hash, full-rate multiply
+        my_added += pend[u] ? 1u : 0u;
+      }
+      uint32_t guard = 0;
+      while (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (!__ballot(pend[u])) continue;   // wave-uniform
+          const uint32_t cur = hkey[h[u]];
+          const bool tryins = pend[u] && cur == SHK_EMPTY;
+          // 0xFFFFFFFE is never stored (tags use 28 bits, SHK_EMPTY is ~0): that compare cannot succeed
+          const uint32_t prev = atomicCAS(&hkey[h[u]], tryins ? SHK_EMPTY : 0xFFFFFFFEu, want[u] | (SHK_MAX_CHUNKS - 1));
+          const bool ins = tryins && prev == SHK_EMPTY;
+          const uint32_t now = cur != SHK_EMPTY ? cur : (ins ? want[u] : prev);
+          const bool match = pend[u] && (now >> SHK_CHUNK_BITS) == (want[u] >> SHK_CHUNK_BITS);
+          const unsigned long long mi = __ballot(ins);
+          if (mi) {   // wave-uniform: first occurrences append their slot to the list
+            const unsigned first = (unsigned)(__ffsll((long long)mi) - 1);
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&s_nlist, (uint32_t)__popcll(mi));
+            base = __shfl(base, first);
+            if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
+          }
+          if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
+          atomicAdd(&hcnt[h[u]], match ? 1u : 0u);
+          pend[u] = pend[u] && !match;
+          h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }
-        if (!placed) { atomicOr(&s_fail, SHK_E_HASH_FULL); continue; }
-        if (A.want_hist) atomicMin(&hkey[h], want | chunk);   // first chunk of the key: only the histogram needs it
-        if (!(A.ablate & 512)) atomicAdd(&hcnt[h], 1u);
-        my_added++;
+        if (++guard > SHK_HCAP) { hfull = pend[0] || pend[1] || pend[2] || pend[3]; break; }
       }
     }
+    if (__ballot(corrupt) && corrupt) atomicOr(A.err, SHK_E_CORRUPT);
+    if (__ballot(hfull) && hfull) atomicOr(&s_fail, SHK_E_HASH_FULL);
   }
   if (my_added) atomicAdd(&s_added, my_added);
   __syncthreads();
@@ -362,9 +389,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
 
   SHK_STAMP(2);   // old structure (rank/select)
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
-  if (!(A.ablate & 16))
-  for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
-    if (hkey[h] != SHK_EMPTY) atomicAdd(&qcnt[hkey[h] >> (SHK_CHUNK_BITS + 8)], 1u);
+  const uint32_t nlist = (A.ablate & 16) ? 0 : s_nlist;
+  for (uint32_t i = tid; i < nlist; i += nthr) atomicAdd(&qcnt[hkey[slist[i]] >> (SHK_CHUNK_BITS + 8)], 1u);
   __syncthreads();
   constexpr uint32_t per = SHK_REGION / nthr;  // consecutive quotients per lane
   const uint32_t qa = tid * per;
@@ -378,12 +404,12 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (tid == nthr - 1) qoff[SHK_REGION] = (uint16_t)ex;
   }
   __syncthreads();
-  for (uint32_t h = tid; h < SHK_HCAP; h += nthr)
-    if (hkey[h] != SHK_EMPTY) {
-      const uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
-      const uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
-      nidx[pos] = (uint16_t)h;
-    }
+  for (uint32_t i = tid; i < nlist; i += nthr) {
+    const uint32_t h = slist[i];
+    const uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
+    const uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
+    nidx[pos] = (uint16_t)h;
+  }
   __syncthreads();
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
@@ -533,8 +559,9 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     // per-chunk histogram from which the host reads the chunk of a deNoise point
     uint16_t *nc = A.newchunks + (size_t)r * SHK_HCAP;
     uint32_t base = 0;
-    for (uint32_t h = tid; h < SHK_HCAP; h += SHK_WAVE) {
-      const bool f = hkey[h] != SHK_EMPTY && (hcnt[h] >> 31);
+    for (uint32_t i0 = 0; i0 < nlist; i0 += SHK_WAVE) {     // nidx[0, nlist) = every hash slot in use
+      const uint32_t h = i0 + tid < nlist ? nidx[i0 + tid] : 0;
+      const bool f = i0 + tid < nlist && (hcnt[h] >> 31);
       const unsigned long long m = __ballot(f);
       if (f) nc[base + (uint32_t)__popcll(m & ((1ULL << tid) - 1))] = (uint16_t)(hkey[h] & (SHK_MAX_CHUNKS - 1));
       base += (uint32_t)__popcll(m);

@@ -63,6 +63,7 @@ struct shk_ctx {
   unsigned long long *d_lb_agg, *d_lb_incl;
   int big_image;                // 1: rebuild kernels run with the SHK_IMG_BLOCKS_BIG image (set after a cluster outgrew the small one)
   int single_ok;                // 1: single-launch rebuild with look-back (SHK_SINGLE=1); 0 after it had to give up once
+  uint32_t merge_group;         // threads per region workgroup (one wave rebuilds; the others help staging and folding)
   int use_spill;                // 1 (default): summary launch spills lengths + encodings, k_region_place writes table B
   uint8_t *d_spill;
   uint32_t *d_over_list;
@@ -225,6 +226,8 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (dmalloc(&c->d_summary, SHK_SUM_STRIDE * (uint64_t)c->nregions + 8)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_lb_agg, (uint64_t)c->nregions + 2) || dmalloc(&c->d_lb_incl, (uint64_t)c->nregions + 2)) return SHK_ERR_HIP;
   c->single_ok = getenv("SHK_SINGLE") ? 1 : 0;
+  c->merge_group = SHK_MERGE_GROUP;
+  if (const char *mg = getenv("SHK_MERGE_GROUP")) { int v = atoi(mg); if (v == 64 || v == 128) c->merge_group = (uint32_t)v; }
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
   if (cfg->num_denoise && !getenv("SHK_COARSE_HIST")) {
     if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
@@ -372,9 +375,9 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
 template <int MODE>
 static void launch_merge(shk_ctx *c, const ShkMergeArgs &A) {
   if (c->big_image)
-    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(c->merge_group), 0, c->stream, A);
   else
-    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_MERGE_GROUP), 0, c->stream, A);
+    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(c->merge_group), 0, c->stream, A);
 }
 
 struct MergeOut {
@@ -600,7 +603,10 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
                             (double)c->cfg.ndistinct_for_denoise;
     // When the trigger is within reach of this batch the first launch also fills the first-chunk
     // histogram, so that a pass which turns out to contain the deNoise point already yields its coarse position.
-    const bool possible = watch && c->ndistinct + nwords >= c->cfg.ndistinct_for_denoise;
+    // (with a known rate of new keys per k-mer, "within reach" means within twice the predicted gain; a
+    // point that is missed this way only costs one more statistics pass)
+    const double reach = c->new_frac > 0 ? 2.0 * c->new_frac * (double)nwords * (double)(hi - lo + 1) / (double)nchunks : (double)nwords;
+    const bool possible = watch && (double)c->ndistinct + reach >= (double)c->cfg.ndistinct_for_denoise;
     if (c->single_ok && !likely) {
       // single-launch scheme: one launch does statistics and table
       rc = merge_single(c, words, lo, hi, 0, &o, possible ? 1 : 0, lo, shift);

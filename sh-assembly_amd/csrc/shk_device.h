@@ -24,7 +24,7 @@
 #define SHK_HCAP_LOG2 9
 #define SHK_HCAP (1u << SHK_HCAP_LOG2)                 // LDS hash capacity (distinct new keys per region)
 #define SHK_MERGE_THREADS 64                           // the rebuild kernels run one wave per region ...
-#define SHK_MERGE_GROUP 256                            // ... helped by three more waves while the batch keys are folded in
+#define SHK_MERGE_GROUP 128                            // ... helped by one more wave while staging and folding the batch keys (the kernel is bound by instruction issue: more helpers only add instructions)
 #define SHK_CHUNK_BITS 12                              // chunk index field of a key word
 #define SHK_MAX_CHUNKS (1u << SHK_CHUNK_BITS)
 #define SHK_HIST_BINS 32
