@@ -131,9 +131,11 @@ int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                       int want_hist, shk_summary *out);
 int shk_stage_commit(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, const shk_summary *s);
-/* single-launch form: shk_stage_try rebuilds [lo, hi] into the spare table and returns the same
- * statistics; shk_stage_accept makes that table the live one (only after a clean try over the
- * same range); otherwise the spare table is simply reused by the next call */
+/* try/accept form (what sh-assembly_amd/shk/dist.py uses): shk_stage_try computes everything about
+ * inserting [lo, hi] that does not depend on the other ranks' decision -- statistics, run lengths and
+ * encodings (kept on the device), free pointers, error flags -- and writes nothing to the live table;
+ * shk_stage_accept then places the runs into the spare table and makes it the live one (only after a
+ * clean try over the same range); a try that is not accepted is simply superseded by the next call */
 int shk_stage_try(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                   int want_hist, shk_summary *out);
 int shk_stage_accept(shk_ctx *ctx, const shk_summary *s);
