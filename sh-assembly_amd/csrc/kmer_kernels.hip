@@ -124,7 +124,8 @@ __global__ void k_scan_chunks(uint64_t *nlines_seg, unsigned nchunks, uint64_t *
 // Line l (0-based, by newline count from the chunk start) is a header when l%4==0 and
 // the read when l%4==1 -- the same strict 4-line walk as CQF_mt.h:616-726.
 __global__ void k_emit_reads(const uint8_t *text, const uint64_t *chunk_off, const uint64_t *chunk_len,
-                             const uint64_t *reads_base, const uint64_t *line_base_seg, uint64_t *rd_start, uint64_t *rd_end) {
+                             const uint64_t *reads_base, const uint64_t *line_base_seg, uint64_t *rd_start, uint64_t *rd_end,
+                             uint16_t *rd_chunk) {
   __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
   __shared__ uint64_t line_carry;
   const unsigned c = blockIdx.x / SHK_PARSE_SEGS, seg = blockIdx.x % SHK_PARSE_SEGS;
@@ -155,7 +156,7 @@ __global__ void k_emit_reads(const uint8_t *text, const uint64_t *chunk_off, con
           uint64_t pos = a0 + 16 * u + 4 * i + (bit >> 3);
           uint64_t rd = line >> 2;
           if (rd < nreads) {
-            if ((line & 3) == 0) rd_start[rbase + rd] = pos + 1;
+            if ((line & 3) == 0) { rd_start[rbase + rd] = pos + 1; rd_chunk[rbase + rd] = (uint16_t)c; }
             else if ((line & 3) == 1) rd_end[rbase + rd] = pos;
           }
           line++;
@@ -184,22 +185,56 @@ __device__ __forceinline__ uint32_t shk_segment_end(const uint8_t *rd, uint32_t 
   return len;
 }
 
+// The first 256 bases of a read, fetched with four independent loads (lane l holds bases l, 64+l, 128+l,
+// 192+l; 0 beyond the end) and their 'N' masks: reads up to 256 bases need no further memory access for
+// the restart rule. These kernels are bound by the latency of dependent loads, not by bandwidth.
+__device__ __forceinline__ void shk_read_preload(const uint8_t *rd, uint32_t len, unsigned lane, uint32_t c[4],
+                                                 unsigned long long nm[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const uint32_t pos = (uint32_t)t * 64 + lane;
+    c[t] = pos < len ? rd[pos] : 0u;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) nm[t] = __ballot(c[t] == 'N');
+}
+__device__ __forceinline__ uint32_t shk_segment_end_pre(const unsigned long long nm[4], const uint8_t *rd, uint32_t len,
+                                                        uint32_t s, uint32_t k) {
+  if (len > 256) return shk_segment_end(rd, len, s, k);
+  const uint32_t from = s + k;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    if ((uint32_t)t < (from >> 6)) continue;
+    unsigned long long m = nm[t];
+    if ((uint32_t)t == (from >> 6)) m &= ~0ULL << (from & 63);
+    if (m) return (uint32_t)t * 64 + (uint32_t)(__ffsll((long long)m) - 1);
+  }
+  return len;
+}
+
 // k-mers per read (one wave per read, grid-stride)
 __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
                              const uint64_t *nreads_p, uint32_t k, uint32_t *nkeys, uint32_t *err) {
   const uint64_t nreads = *nreads_p;
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
-  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + shk_wave(); r < nreads; r += nwaves) {
-    const uint64_t st = rd_start[r], en = rd_end[r];
+  uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + shk_wave();
+  uint64_t st_n = 0, en_n = 0;
+  if (r < nreads) { st_n = rd_start[r]; en_n = rd_end[r]; }
+  for (; r < nreads; r += nwaves) {
+    const uint64_t st = st_n, en = en_n;
+    if (r + nwaves < nreads) { st_n = rd_start[r + nwaves]; en_n = rd_end[r + nwaves]; }   // next read's extent is in flight
     uint32_t cnt = 0;
     if (en - st > SHK_MAX_READ) {
       if (shk_lane() == 0) atomicOr(err, SHK_E_BAD_FASTQ);
     } else {
       const uint32_t len = (uint32_t)(en - st);
       const uint8_t *rd = text + st;
+      uint32_t c[4];
+      unsigned long long nm[4];
+      shk_read_preload(rd, len, shk_lane(), c, nm);
       uint32_t s = 0;
       while (len >= s + k) {
-        uint32_t e = shk_segment_end(rd, len, s, k);
+        uint32_t e = shk_segment_end_pre(nm, rd, len, s, k);
         cnt += e - s - k + 1;
         if (e == len) break;
         s = e + 1;
@@ -212,7 +247,7 @@ __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, cons
 // ---------------------------------------------------------------- hash
 // word = key | chunk << hb, key = min(fh, rh) mod 2^hb (CQF_mt.h:636-637, gqf.c:2230).
 __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
-                             const uint64_t *nreads_p, const uint64_t *reads_base, uint32_t nchunks,
+                             const uint64_t *nreads_p, const uint16_t *rd_chunk,
                              uint32_t chunk_first, const uint64_t *key_base, uint32_t k, uint32_t hb,
                              uint64_t *words, uint64_t cap, uint32_t *err) {
   __shared__ uint64_t ringG[SHK_HASH_WAVES][256];  // launched with at most SHK_HASH_WAVES waves per group
@@ -230,23 +265,27 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
                  rT = shk_rol64(SHK_SEED_A, lane);   // complement seeds (nthash.hpp:15,299)
   const unsigned rot_f = lane;                        // (k - 1 + p) & 63 with p = j + 1 - k
   const unsigned rot_r = (lane + 1 + 64 * 4 - k) & 63;  // p & 63 (k <= 191 < 256)
-  for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + wv; r < nreads; r += nwaves) {
-    const uint64_t st = rd_start[r], en = rd_end[r];
+  uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + wv;
+  uint64_t st_n = 0, en_n = 0, kb_n = 0;
+  uint32_t ch_n = 0;
+  if (r < nreads) { st_n = rd_start[r]; en_n = rd_end[r]; kb_n = key_base[r]; ch_n = rd_chunk[r]; }
+  for (; r < nreads; r += nwaves) {
+    const uint64_t st = st_n, en = en_n;
+    uint64_t out = kb_n;
+    const uint64_t chunk_tag = (uint64_t)(chunk_first + ch_n) << hb;
+    if (r + nwaves < nreads) {   // the next read's table entries are in flight while this one is hashed
+      st_n = rd_start[r + nwaves]; en_n = rd_end[r + nwaves]; kb_n = key_base[r + nwaves]; ch_n = rd_chunk[r + nwaves];
+    }
     if (en - st > SHK_MAX_READ) continue;
     const uint32_t len = (uint32_t)(en - st);
     if (len < k) continue;
-    // chunk of this read: last c with reads_base[c] <= r (wave-uniform binary search)
-    uint32_t lo = 0, hi = nchunks;
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) / 2;
-      if (reads_base[mid] <= r) lo = mid; else hi = mid;
-    }
-    const uint64_t chunk_tag = (uint64_t)(chunk_first + lo) << hb;
     const uint8_t *rd = text + st;
-    uint64_t out = key_base[r];
+    uint32_t pc[4];
+    unsigned long long nm[4];
+    shk_read_preload(rd, len, lane, pc, nm);
     uint32_t s = 0;
     while (len >= s + k) {
-      const uint32_t e = shk_segment_end(rd, len, s, k);
+      const uint32_t e = shk_segment_end_pre(nm, rd, len, s, k);
       const uint32_t L = e - s;             // bases in this segment
       const uint32_t nk = L - k + 1;        // its k-mers
       if (out + nk > cap) {
@@ -259,7 +298,9 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
         const uint32_t j = t * 64 + lane;   // index in the segment
         uint64_t a = 0, c = 0;
         if (j < L) {
-          const unsigned ch = rd[s + j] & 0xDF;   // upper and lower case map alike (nthash.hpp:85-153); all else is 0
+          // the first segment's first four strips are already in registers
+          const uint32_t raw = (s == 0 && t < 4) ? (t == 0 ? pc[0] : t == 1 ? pc[1] : t == 2 ? pc[2] : pc[3]) : (uint32_t)rd[s + j];
+          const unsigned ch = raw & 0xDF;   // upper and lower case map alike (nthash.hpp:85-153); all else is 0
           a = ch == 'A' ? fA : ch == 'C' ? fC : ch == 'G' ? fG : ch == 'T' ? fT : 0ULL;
           c = ch == 'A' ? rA : ch == 'C' ? rC : ch == 'G' ? rG : ch == 'T' ? rT : 0ULL;
         }

@@ -49,6 +49,7 @@ struct shk_ctx {
   uint8_t *d_text;
   uint64_t *d_chunk_off, *d_chunk_len, *d_nlines, *d_reads_base;
   uint64_t *d_rd_start, *d_rd_end;
+  uint16_t *d_rd_chunk;         // chunk (within the call) of every read
   uint32_t *d_nkeys;
   uint64_t *d_key_base;
   uint64_t *d_words[2];
@@ -203,7 +204,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (dmalloc(&c->d_chunk_off, maxch) || dmalloc(&c->d_chunk_len, maxch) || dmalloc(&c->d_nlines, (uint64_t)maxch * SHK_PARSE_SEGS) ||
       dmalloc(&c->d_reads_base, maxch + 1)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_rd_start, c->max_reads + 1) || dmalloc(&c->d_rd_end, c->max_reads + 1) ||
-      dmalloc(&c->d_nkeys, c->max_reads + 1) || dmalloc(&c->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
+      dmalloc(&c->d_nkeys, c->max_reads + 1) || dmalloc(&c->d_rd_chunk, c->max_reads + 1) || dmalloc(&c->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_scalars, 64)) return SHK_ERR_HIP;
   HIPCHK(hipMemsetAsync(c->d_scalars, 0, 64 * 8, c->stream));
   {
@@ -264,7 +265,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   for (size_t i = 0; i < c->evpool.size(); i++) hipEventDestroy(c->evpool[i]);
   for (int i = 0; i < 2; i++) { hipFree(c->tab[i]); hipFree(c->fin[i]); hipFree(c->d_words[i]); }
   hipFree(c->d_text); hipFree(c->d_chunk_off); hipFree(c->d_chunk_len); hipFree(c->d_nlines); hipFree(c->d_reads_base);
-  hipFree(c->d_rd_start); hipFree(c->d_rd_end); hipFree(c->d_nkeys); hipFree(c->d_key_base); hipFree(c->d_scalars);
+  hipFree(c->d_rd_start); hipFree(c->d_rd_end); hipFree(c->d_rd_chunk); hipFree(c->d_nkeys); hipFree(c->d_key_base); hipFree(c->d_scalars);
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
@@ -323,7 +324,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   if (nreads > c->max_reads) return SHK_ERR_BATCH;
   { ProfScope ps(c, KP_EMIT_READS);
     hipLaunchKernelGGL(k_emit_reads, dim3(nchunks * SHK_PARSE_SEGS), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len,
-                       c->d_reads_base, c->d_nlines, c->d_rd_start, c->d_rd_end); }
+                       c->d_reads_base, c->d_nlines, c->d_rd_start, c->d_rd_end, c->d_rd_chunk); }
   uint32_t groups = c->hash_groups;
   { uint64_t need = nreads / (c->threads / SHK_WAVE) + 1; if (need < groups) groups = (uint32_t)need; }
   { ProfScope ps(c, KP_COUNT_KEYS);
@@ -335,7 +336,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   { ProfScope ps(c, KP_HASH);
     const uint32_t ht = c->threads < SHK_HASH_WAVES * SHK_WAVE ? c->threads : SHK_HASH_WAVES * SHK_WAVE;
     hipLaunchKernelGGL(k_hash_reads, dim3(groups * (c->threads / ht)), dim3(ht), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
-                       c->d_scalars + 0, c->d_reads_base, nchunks, chunk_first, c->d_key_base, c->cfg.k, c->cfg.hb,
+                       c->d_scalars + 0, c->d_rd_chunk, chunk_first, c->d_key_base, c->cfg.k, c->cfg.hb,
                        c->d_words[0], c->cfg.max_batch_keys, c->d_err); }
   HIPCHK(hipGetLastError());
   return SHK_OK;
