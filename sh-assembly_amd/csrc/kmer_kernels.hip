@@ -188,13 +188,15 @@ __device__ __forceinline__ uint32_t shk_segment_end(const uint8_t *rd, uint32_t 
 // The first 256 bases of a read, fetched with four independent loads (lane l holds bases l, 64+l, 128+l,
 // 192+l; 0 beyond the end) and their 'N' masks: reads up to 256 bases need no further memory access for
 // the restart rule. These kernels are bound by the latency of dependent loads, not by bandwidth.
-__device__ __forceinline__ void shk_read_preload(const uint8_t *rd, uint32_t len, unsigned lane, uint32_t c[4],
-                                                 unsigned long long nm[4]) {
+__device__ __forceinline__ void shk_read_bytes(const uint8_t *text, uint64_t st, uint64_t en, unsigned lane, uint32_t c[4]) {
+  const uint64_t len = en > st ? en - st : 0;
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     const uint32_t pos = (uint32_t)t * 64 + lane;
-    c[t] = pos < len ? rd[pos] : 0u;
+    c[t] = pos < len ? text[st + pos] : 0u;
   }
+}
+__device__ __forceinline__ void shk_read_masks(const uint32_t c[4], unsigned long long nm[4]) {
 #pragma unroll
   for (int t = 0; t < 4; t++) nm[t] = __ballot(c[t] == 'N');
 }
@@ -218,20 +220,28 @@ __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, cons
   const uint64_t nreads = *nreads_p;
   const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
   uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + shk_wave();
-  uint64_t st_n = 0, en_n = 0;
+  // two reads ahead for the table entries, one read ahead for the bases: all loads of a read are in
+  // flight while the previous one is counted
+  uint64_t st_n = 0, en_n = 0, st_nn = 0, en_nn = 0;
+  uint32_t c[4], c_n[4];
   if (r < nreads) { st_n = rd_start[r]; en_n = rd_end[r]; }
+  if (r + nwaves < nreads) { st_nn = rd_start[r + nwaves]; en_nn = rd_end[r + nwaves]; }
+  shk_read_bytes(text, st_n, en_n, shk_lane(), c_n);
   for (; r < nreads; r += nwaves) {
     const uint64_t st = st_n, en = en_n;
-    if (r + nwaves < nreads) { st_n = rd_start[r + nwaves]; en_n = rd_end[r + nwaves]; }   // next read's extent is in flight
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = c_n[t];
+    st_n = st_nn; en_n = en_nn;
+    if (r + nwaves < nreads) shk_read_bytes(text, st_n, en_n, shk_lane(), c_n);
+    if (r + 2 * nwaves < nreads) { st_nn = rd_start[r + 2 * nwaves]; en_nn = rd_end[r + 2 * nwaves]; }
     uint32_t cnt = 0;
     if (en - st > SHK_MAX_READ) {
       if (shk_lane() == 0) atomicOr(err, SHK_E_BAD_FASTQ);
     } else {
       const uint32_t len = (uint32_t)(en - st);
       const uint8_t *rd = text + st;
-      uint32_t c[4];
       unsigned long long nm[4];
-      shk_read_preload(rd, len, shk_lane(), c, nm);
+      shk_read_masks(c, nm);
       uint32_t s = 0;
       while (len >= s + k) {
         uint32_t e = shk_segment_end_pre(nm, rd, len, s, k);
@@ -266,23 +276,30 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
   const unsigned rot_f = lane;                        // (k - 1 + p) & 63 with p = j + 1 - k
   const unsigned rot_r = (lane + 1 + 64 * 4 - k) & 63;  // p & 63 (k <= 191 < 256)
   uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + wv;
-  uint64_t st_n = 0, en_n = 0, kb_n = 0;
-  uint32_t ch_n = 0;
+  // two reads ahead for the table entries, one read ahead for the bases (see k_count_keys)
+  uint64_t st_n = 0, en_n = 0, kb_n = 0, st_nn = 0, en_nn = 0, kb_nn = 0;
+  uint32_t ch_n = 0, ch_nn = 0;
+  uint32_t pc[4], pc_n[4];
   if (r < nreads) { st_n = rd_start[r]; en_n = rd_end[r]; kb_n = key_base[r]; ch_n = rd_chunk[r]; }
+  if (r + nwaves < nreads) { st_nn = rd_start[r + nwaves]; en_nn = rd_end[r + nwaves]; kb_nn = key_base[r + nwaves]; ch_nn = rd_chunk[r + nwaves]; }
+  shk_read_bytes(text, st_n, en_n, lane, pc_n);
   for (; r < nreads; r += nwaves) {
     const uint64_t st = st_n, en = en_n;
     uint64_t out = kb_n;
     const uint64_t chunk_tag = (uint64_t)(chunk_first + ch_n) << hb;
-    if (r + nwaves < nreads) {   // the next read's table entries are in flight while this one is hashed
-      st_n = rd_start[r + nwaves]; en_n = rd_end[r + nwaves]; kb_n = key_base[r + nwaves]; ch_n = rd_chunk[r + nwaves];
+#pragma unroll
+    for (int t = 0; t < 4; t++) pc[t] = pc_n[t];
+    st_n = st_nn; en_n = en_nn; kb_n = kb_nn; ch_n = ch_nn;
+    if (r + nwaves < nreads) shk_read_bytes(text, st_n, en_n, lane, pc_n);
+    if (r + 2 * nwaves < nreads) {
+      st_nn = rd_start[r + 2 * nwaves]; en_nn = rd_end[r + 2 * nwaves]; kb_nn = key_base[r + 2 * nwaves]; ch_nn = rd_chunk[r + 2 * nwaves];
     }
     if (en - st > SHK_MAX_READ) continue;
     const uint32_t len = (uint32_t)(en - st);
     if (len < k) continue;
     const uint8_t *rd = text + st;
-    uint32_t pc[4];
     unsigned long long nm[4];
-    shk_read_preload(rd, len, lane, pc, nm);
+    shk_read_masks(pc, nm);
     uint32_t s = 0;
     while (len >= s + k) {
       const uint32_t e = shk_segment_end_pre(nm, rd, len, s, k);
