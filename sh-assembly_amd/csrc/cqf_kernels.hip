@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         h[u] = (__umul24(tag, 40503u) & 0xFFFFu) >> (16 - SHK_HCAP_LOG2);   // 16-bit multiplicative hash, full-rate multiply
         my_added += pend[u] ? 1u : 0u;
       }
+      if (A.ablate & 256) continue;   // diagnostics: loads + setup only
       uint32_t guard = 0;
       while (__ballot(pend[0] || pend[1] || pend[2] || pend[3])) {
 #pragma unroll
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }
+        if (A.ablate & 512) break;      // diagnostics: one probe step only
         if (++guard > SHK_HCAP) { hfull = pend[0] || pend[1] || pend[2] || pend[3]; break; }
       }
     }
@@ -432,96 +434,114 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   uint32_t st_used = 0;            // staged bytes of this lane
   bool st_over = false;            // a run did not fit: this lane re-merges at placement time
   uint8_t *mystage = stage + tid * SHK_STAGE_PER_LANE;
-  for (uint32_t j = 0; j < per; j++) {
-    const uint32_t q = qa + j;
-    uint32_t len = 0;
-    if (q < nq && !fatal && !(A.ablate & 2)) {
-      const bool occ = (oocc[q >> 6] >> (q & 63)) & 1;
-      uint32_t opos = 0, oend = 0;
-      bool ohas = false;
-      if (occ) {
-        const uint32_t jr = oorank[q >> 6] + (uint32_t)__popcll(oocc[q >> 6] & ((1ULL << (q & 63)) - 1));
-        oend = orend[jr];
-        opos = jr ? (uint32_t)orend[jr - 1] + 1 : olo;
-        if (opos < q) opos = q;
-        ohas = true;
-      }
-      uint32_t ni = qoff[q];
-      const uint32_t ne = qoff[q + 1];
-      uint32_t orem = 0, on = 0; uint64_t ocnt = 0;
-      if (ohas) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
-      uint32_t nrem = 256, nh = 0, nkey = 0;
-      if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
-      while (ohas || ni < ne) {
-        uint32_t rem; uint64_t total; bool is_new = false; bool prot = false; uint32_t mc = 0;
-        bool adv = false;
-        uint32_t nhx = 0;
-        if (ohas && orem <= nrem) {
-          rem = orem; total = ocnt;
-          if (A.denoise) {
-            // protected singleton: k_denoise_marks set its traveled bit in table A
-            const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
-            prot = (oimg[tb] >> (opos & 7)) & 1;
-          }
-          // a deNoise round drops the OLD singleton first; words of this pass (chunks behind the
-          // deNoise point) then count as if the key had never been seen (qf_clean_singleton, then inserts)
-          const bool drop = A.denoise && ocnt < 2 && !prot;
-          if (drop) { my_removed++; total = 0; }
-          if (orem == nrem) {
-            total += hcnt[nh]; adv = true;
-            if (drop) { is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); nhx = nh; }
-          }
-          opos += on;
-          if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt); else ohas = false;
-        } else {
-          rem = nrem; total = hcnt[nh]; is_new = true; mc = nkey & (SHK_MAX_CHUNKS - 1); adv = true; nhx = nh;
-        }
-        if (adv) {
-          ni++;
-          nrem = 256;
-          if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; nrem = (nkey >> SHK_CHUNK_BITS) & 0xff; }
-        }
-        if (total == 0) continue;
-        if (is_new) {
-          my_new++;
-          if (MODE != 1 && A.want_hist) {
-            // exact mode: the key is only flagged here and its first chunk collected below (the count
-            // was consumed above); the coarse histogram would cost one global atomic per bin and region
-            if (A.newchunks) hcnt[nhx] |= 0x80000000u;
-            else if (mc < A.hist_base) my_before++;
-            else {
-              uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
-              atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
-            }
-          }
-        }
-        const unsigned el = shk_enc_len_fast(rem, total);
-        if (STAGE) {
-          if (!st_over && st_used + el <= SHK_STAGE_PER_LANE) {
-            if (total <= 128) {           // fast encode
-              mystage[st_used] = (uint8_t)rem;
-              if (total > 1) {
-                const unsigned cdig = (unsigned)(total - 1);
-                unsigned o = 1;
-                if (cdig > rem) mystage[st_used + o++] = 0;
-                mystage[st_used + o] = (uint8_t)cdig;
-              }
-            } else {
-              uint8_t enc[12];
-              const unsigned n = shk_enc_write(enc, rem, total);
-              for (unsigned i = 0; i < n; i++) mystage[st_used + i] = enc[i];
-            }
-            st_used += el;
-          } else st_over = true;
-        }
-        len += el;
-      }
-      if (len) {
-        ShkMP m; m.a = len; m.b = (long long)q + len;
-        mine = shk_mp_compose(mine, m);
-      }
+  // The lane's four quotients are merged in ONE loop over (quotient, remainder) order: the old entries
+  // of its runs on one side, its new keys (nidx is sorted the same way) on the other. A wave runs the
+  // loop as often as its busiest lane has entries -- about half of what four per-quotient loops cost.
+  if (qa < nq && !fatal && !(A.ablate & 2)) {
+    const uint64_t ow = oocc[qa >> 6];
+    uint32_t occ4 = (uint32_t)(ow >> (qa & 63)) & ((1u << per) - 1);          // which of my quotients had a run
+    uint32_t jr = oorank[qa >> 6] + (uint32_t)__popcll(ow & ((1ULL << (qa & 63)) - 1));  // index of my first old run
+    uint32_t oprev = jr ? (uint32_t)orend[jr - 1] + 1 : olo;                  // first slot behind the previous old run
+    uint32_t oq = 0, opos = 0, oend = 0, orem = 0, on = 0;
+    uint64_t ocnt = 0;
+    bool ohas = false;
+    if (occ4) {
+      oq = qa + (uint32_t)__ffs((int)occ4) - 1; occ4 &= occ4 - 1;
+      oend = orend[jr];
+      opos = oprev > oq ? oprev : oq;
+      on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
+      ohas = true;
     }
-    qcnt[q] = len;
+    uint32_t ni = qoff[qa];
+    const uint32_t ne = qoff[qa + per];
+    uint32_t nh = 0, nkey = 0;
+    constexpr uint32_t NONE = 0xFFFFFFu;
+    uint32_t ncomp = NONE;                                                   // quotient << 8 | remainder of the next new key
+    if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
+    uint32_t curq = 0xFFFFFFFFu, len = 0;
+    while (ohas || ni < ne) {
+      const uint32_t ocomp = ohas ? ((oq << 8) | orem) : NONE;
+      const uint32_t comp = ocomp < ncomp ? ocomp : ncomp;
+      const bool take_old = ocomp == comp, take_new = ncomp == comp;
+      const uint32_t eq = comp >> 8, rem = comp & 0xff;
+      if (eq != curq) {                     // the previous quotient's run is complete
+        if (len) {
+          qcnt[curq] = len;
+          ShkMP m; m.a = len; m.b = (long long)curq + len;
+          mine = shk_mp_compose(mine, m);
+        }
+        curq = eq; len = 0;
+      }
+      uint64_t total = 0;
+      bool is_new = false;
+      uint32_t mc = 0, nhx = 0;
+      if (take_old) {
+        total = ocnt;
+        if (A.denoise) {
+          // a deNoise round drops the OLD singleton unless k_denoise_marks protected it (traveled bit in table A);
+          // words of this pass (chunks behind the deNoise point) then count as if the key had never been seen
+          const uint32_t tb = (opos >> 6) * SHK_BLOCK_BYTES + SHK_OFF_TRAV + ((opos & 63) >> 3);
+          const bool prot = (oimg[tb] >> (opos & 7)) & 1;
+          if (ocnt < 2 && !prot) { my_removed++; total = 0; is_new = true; }
+        }
+        opos += on;
+        if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
+        else if (occ4) {                    // my next old run
+          oq = qa + (uint32_t)__ffs((int)occ4) - 1; occ4 &= occ4 - 1;
+          jr++;
+          oprev = oend + 1;
+          oend = orend[jr];
+          opos = oprev > oq ? oprev : oq;
+          on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
+        } else ohas = false;
+      } else is_new = true;
+      if (take_new) {
+        total += hcnt[nh];
+        mc = nkey & (SHK_MAX_CHUNKS - 1); nhx = nh;
+        ni++;
+        ncomp = NONE;
+        if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
+      } else is_new = false;
+      if (total == 0) continue;
+      if (is_new) {
+        my_new++;
+        if (MODE != 1 && A.want_hist) {
+          // exact mode: the key is only flagged here and its first chunk collected below (the count
+          // was consumed above); the coarse histogram would cost one global atomic per bin and region
+          if (A.newchunks) hcnt[nhx] |= 0x80000000u;
+          else if (mc < A.hist_base) my_before++;
+          else {
+            uint32_t bin = (mc - A.hist_base) >> A.hist_shift;
+            atomicAdd(&lhist[bin < SHK_HIST_BINS ? bin : SHK_HIST_BINS - 1], 1u);
+          }
+        }
+      }
+      const unsigned el = shk_enc_len_fast(rem, total);
+      if (STAGE) {
+        if (!st_over && st_used + el <= SHK_STAGE_PER_LANE) {
+          if (total <= 128) {           // fast encode
+            mystage[st_used] = (uint8_t)rem;
+            if (total > 1) {
+              const unsigned cdig = (unsigned)(total - 1);
+              unsigned o = 1;
+              if (cdig > rem) mystage[st_used + o++] = 0;
+              mystage[st_used + o] = (uint8_t)cdig;
+            }
+          } else {
+            uint8_t enc[12];
+            const unsigned n = shk_enc_write(enc, rem, total);
+            for (unsigned i = 0; i < n; i++) mystage[st_used + i] = enc[i];
+          }
+          st_used += el;
+        } else st_over = true;
+      }
+      len += el;
+    }
+    if (len) {
+      qcnt[curq] = len;
+      ShkMP m; m.a = len; m.b = (long long)curq + len;
+      mine = shk_mp_compose(mine, m);
+    }
   }
   SHK_STAMP(4);   // merge pass
   // wave scan of the free-pointer functions (lane order = quotient order)
