@@ -28,7 +28,7 @@ struct ShkMergeArgs {
   uint8_t *tabB;
   const uint64_t *finA;         // [nregions+1] free pointer at each region start of A
   uint64_t *finB;               // same for B (write pass input; written by the single-launch rebuild)
-  const uint64_t *words;        // keys sorted by region; null when there are none
+  const uint32_t *words;        // 32-bit records sorted by region (written by the last partition level); null when there are none
   const uint64_t *region_base;  // [nregions+1] offsets into words
   uint64_t nslots, xnslots, nblocks;
   uint64_t q_lo;
@@ -277,34 +277,32 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   uint32_t my_added = 0;
   if (A.words && !fatal && !(A.ablate & 1)) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
-    const uint64_t kmask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
     const unsigned lane = shk_lane();
     const bool wh = A.want_hist != 0;
     bool corrupt = false, hfull = false;
     const uint32_t nw = (uint32_t)(ke - kb);   // a region's share of one batch is far below 2^32 words
-    const uint64_t *wp = A.words + kb;
+    const uint32_t *wp = A.words + kb;
     for (uint32_t i0 = 0; i0 < nw; i0 += 4 * ngrp) {
-      uint64_t wv[4];
+      uint32_t wv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t i = i0 + (uint32_t)u * ngrp + tid;
-        wv[u] = i < nw ? wp[i] : ~0ULL;
+        wv[u] = i < nw ? wp[i] : ~0u;
       }
       uint32_t h[4], want[4], chk[4];
       bool pend[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const uint64_t w = wv[u];
+        // record = (quotient in region << 8 | remainder) << SHK_CHUNK_BITS | chunk (k_rp_scatter, last level)
+        const uint32_t w = wv[u];
         const bool in = i0 + (uint32_t)u * ngrp + tid < nw;
-        const uint32_t chunk = (uint32_t)(w >> A.hb);
-        const uint64_t key = w & kmask;
-        const uint32_t ql = (uint32_t)((key >> 8) - A.q_lo - q0);
+        const uint32_t chunk = w & (SHK_MAX_CHUNKS - 1);
+        const uint32_t tag = (w >> SHK_CHUNK_BITS) & 0xFFFFu;
         const bool inr = in && chunk >= A.chunk_lo && chunk <= A.chunk_hi;
-        corrupt |= inr && ql >= nq;
-        pend[u] = inr && ql < nq;
-        const uint32_t tag = ((ql << 8) | (uint32_t)(key & 0xff)) & 0xFFFFu;
+        corrupt |= inr && (tag >> 8) >= nq;
+        pend[u] = inr && (tag >> 8) < nq;
         want[u] = tag << SHK_CHUNK_BITS;
-        chk[u] = chunk & (SHK_MAX_CHUNKS - 1);
+        chk[u] = chunk;
         h[u] = (__umul24(tag, 40503u) & 0xFFFFu) >> (16 - SHK_HCAP_LOG2);   // 16-bit multiplicative hash, full-rate multiply
         my_added += pend[u] ? 1u : 0u;
       }

@@ -18,6 +18,8 @@ struct ShkRpLevel {
   uint32_t nbuckets;  // buckets entering this level (= product of earlier P's)
   uint32_t hb;
   uint64_t q_lo;      // first quotient this context owns (multi-GPU shards)
+  uint64_t nslots;    // quotients this context owns
+  uint32_t out32;     // 1 (last level): write 32-bit records (quotient in region << 8 | remainder) << SHK_CHUNK_BITS | chunk
 };
 
 __device__ __forceinline__ uint32_t shk_word_region(uint64_t w, uint32_t hb, uint64_t q_lo) {
@@ -142,7 +144,7 @@ __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint
 #define SHK_RP_KPT (SHK_RP_TILE / SHK_RP_THREADS)
 __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
                                                                const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
-                                                               uint64_t *cursor) {
+                                                               uint64_t *cursor, uint32_t *err) {
   __shared__ uint32_t lh[SHK_RP_MAXP];      // digit counts (= next rank while counting)
   __shared__ uint32_t lbase[SHK_RP_MAXP];   // local exclusive base of each digit
   __shared__ uint64_t gbase[SHK_RP_MAXP];   // reserved global base of each digit
@@ -199,7 +201,18 @@ __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *i
     for (uint32_t i = threadIdx.x; i < cnt; i += SHK_RP_THREADS) {
       uint64_t x = stage[i];
       uint32_t d = (shk_word_region(x, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-      out[gbase[d] + (i - lbase[d])] = x;
+      if (lv.out32) {
+        // behind the last level a word's region is its bucket: the rebuild kernel only needs the
+        // quotient inside the region, the remainder and the chunk -- half the bytes, no 64-bit arithmetic
+        const uint64_t key = lv.hb >= 64 ? x : (x & ((1ULL << lv.hb) - 1));
+        const uint64_t q = (key >> 8) - lv.q_lo;
+        if (q >= lv.nslots) atomicOr(err, SHK_E_CORRUPT);
+        const uint32_t rec = ((((uint32_t)q & (SHK_REGION - 1)) << 8 | (uint32_t)(key & 0xff)) << SHK_CHUNK_BITS) |
+                             ((uint32_t)(x >> lv.hb) & (SHK_MAX_CHUNKS - 1));
+        reinterpret_cast<uint32_t *>(out)[gbase[d] + (i - lbase[d])] = rec;
+      } else {
+        out[gbase[d] + (i - lbase[d])] = x;
+      }
     }
     __syncthreads();
   }

@@ -178,6 +178,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   const uint32_t mlb = cfg->max_level_bits ? cfg->max_level_bits : 10;
   if (mlb > 10) { delete c; return SHK_ERR_ARG; }
   c->nlevels = (c->rbits + mlb - 1) / mlb;
+  if (c->nlevels == 0) c->nlevels = 1;   // one region: a single pass still converts the words to 32-bit records
   if (c->nlevels > 4) { delete c; return SHK_ERR_ARG; }
   {
     uint32_t left = c->rbits, nb = 1;
@@ -185,8 +186,10 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
       uint32_t bits = (left + (c->nlevels - l) - 1) / (c->nlevels - l);
       left -= bits;
       c->lv[l].shift = left; c->lv[l].bits = bits; c->lv[l].nbuckets = nb; c->lv[l].hb = cfg->hb; c->lv[l].q_lo = c->q_lo;
+      c->lv[l].nslots = c->nslots; c->lv[l].out32 = 0;
       nb <<= bits;
     }
+    c->lv[c->nlevels - 1].out32 = 1;
   }
   c->threads = cfg->threads_per_group ? cfg->threads_per_group : 512;
   if (c->threads < 64 || c->threads > 1024 || (c->threads & (c->threads - 1))) { delete c; return SHK_ERR_ARG; }
@@ -362,7 +365,7 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
     HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
     { ProfScope ps(c, KP_RP_SCATTER);
       hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[cur], c->d_words[cur ^ 1], n_p,
-                         c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor); }
+                         c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor, c->d_err); }
     cur ^= 1;
   }
   if (c->nlevels == 0) {
@@ -393,7 +396,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->want_hist = want_hist;
   A->tabA = c->tab[c->cur]; A->tabB = c->tab[c->cur ^ 1];
   A->finA = c->fin[c->cur]; A->finB = c->fin[c->cur ^ 1];
-  A->words = words; A->region_base = c->d_base[c->nlevels];
+  A->words = reinterpret_cast<const uint32_t *>(words); A->region_base = c->d_base[c->nlevels];
   A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
@@ -825,6 +828,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   // one partition level over the WHOLE filter's regions: digit = owner
   ShkRpLevel lv;
   lv.shift = (c->cfg.qb - SHK_REGION_LOG2) - lg; lv.bits = lg; lv.nbuckets = 1; lv.hb = c->cfg.hb; lv.q_lo = 0;
+  lv.nslots = ~0ULL; lv.out32 = 0;
   c->h_pinned[43] = nwords;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
   const uint64_t *n_p = c->d_scalars + 1;
@@ -849,7 +853,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   (void)base;
   { ProfScope ps(c, KP_RP_SCATTER);
     hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], c->d_words[1], n_p,
-                       c->d_base[0], c->d_tfb, lv, cursor); }
+                       c->d_base[0], c->d_tfb, lv, cursor, c->d_err); }
   HIPCHK(hipGetLastError());
   *d_out = c->d_words[1];
   return finish(c, 0);
