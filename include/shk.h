@@ -95,7 +95,10 @@ int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_
                      shk_batch_stats *stats);
 
 /* Hash only: leaves `*nwords` key words (key | chunk_index << hb, reference emission
- * order) in a context-owned device buffer `*d_words`, valid until the next call. */
+ * order) in a context-owned device buffer `*d_words`, valid until the next call.
+ * In a context that is one of G shards, chunk i of the call is labelled i * G + shard_index:
+ * the ranks' chunks interleave like the parts of the reference's round-robin file queue
+ * (cqf/CQF_mt.h:364-390, 828-830), and nchunks * G must stay below 4096. */
 int shk_hash_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
                     const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
                     uint64_t **d_words, uint64_t *nwords);
@@ -142,8 +145,8 @@ int shk_stage_accept(shk_ctx *ctx, const shk_summary *s);
 /* want_hist = 2 in shk_stage_summary / shk_stage_try additionally records the first chunk of every
  * new key; this call returns the exact histogram of that last pass: out[i] = new keys first seen in
  * chunk i, for i < n (n <= chunk_hi + 1 of the pass). With it the ranks find the chunk of a deNoise
- * point in one pass instead of refining the 32-bin histogram. SHK_ERR_ARG when the last pass has none
- * (contexts created with num_denoise = 0 never have one). */
+ * point in one pass instead of refining the 32-bin histogram. SHK_ERR_ARG when the last pass has none.
+ * (The first want_hist = 2 pass allocates nregions KiB of device memory for the first-chunk records.) */
 int shk_stage_chunk_hist(shk_ctx *ctx, uint64_t *out, uint32_t n);
 
 /* One deNoise round now (the reference's --endDeNoise round; does not use up num_denoise). */

@@ -258,7 +258,7 @@ __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, cons
 // word = key | chunk << hb, key = min(fh, rh) mod 2^hb (CQF_mt.h:636-637, gqf.c:2230).
 __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
                              const uint64_t *nreads_p, const uint16_t *rd_chunk,
-                             uint32_t chunk_first, const uint64_t *key_base, uint32_t k, uint32_t hb,
+                             uint32_t chunk_first, uint32_t chunk_mul, const uint64_t *key_base, uint32_t k, uint32_t hb,
                              uint64_t *words, uint64_t cap, uint32_t *err) {
   __shared__ uint64_t ringG[SHK_HASH_WAVES][256];  // launched with at most SHK_HASH_WAVES waves per group
   __shared__ uint64_t ringH[SHK_HASH_WAVES][256];
@@ -286,7 +286,7 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
   for (; r < nreads; r += nwaves) {
     const uint64_t st = st_n, en = en_n;
     uint64_t out = kb_n;
-    const uint64_t chunk_tag = (uint64_t)(chunk_first + ch_n) << hb;
+    const uint64_t chunk_tag = (uint64_t)(chunk_first + ch_n * chunk_mul) << hb;
 #pragma unroll
     for (int t = 0; t < 4; t++) pc[t] = pc_n[t];
     st_n = st_nn; en_n = en_nn; kb_n = kb_nn; ch_n = ch_nn;

@@ -233,10 +233,6 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->merge_group = SHK_MERGE_GROUP;
   if (const char *mg = getenv("SHK_MERGE_GROUP")) { int v = atoi(mg); if (v == 64 || v == 128) c->merge_group = (uint32_t)v; }
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
-  if (cfg->num_denoise && !getenv("SHK_COARSE_HIST")) {
-    if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
-    HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
-  }
   if (dmalloc(&c->d_spill, (uint64_t)c->nregions * SHK_SPILL_STRIDE) || dmalloc(&c->d_over_list, (uint64_t)c->nregions + 1)) return SHK_ERR_HIP;
   { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
     if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
@@ -303,8 +299,9 @@ static int fetch_err(shk_ctx *c, uint32_t *bits) {
 
 // text + chunk table -> key words in d_words[0]; d_scalars[1] = #words
 static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
-                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first) {
-  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + nchunks > SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
+  // chunk i of this call is labelled chunk_first + i * chunk_mul
+  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
   for (uint32_t i = 0; i < nchunks; i++)
     if (chunk_off[i] + chunk_len[i] > text_bytes) return SHK_ERR_ARG;
   const uint8_t *dtext;
@@ -339,7 +336,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   { ProfScope ps(c, KP_HASH);
     const uint32_t ht = c->threads < SHK_HASH_WAVES * SHK_WAVE ? c->threads : SHK_HASH_WAVES * SHK_WAVE;
     hipLaunchKernelGGL(k_hash_reads, dim3(groups * (c->threads / ht)), dim3(ht), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
-                       c->d_scalars + 0, c->d_rd_chunk, chunk_first, c->d_key_base, c->cfg.k, c->cfg.hb,
+                       c->d_scalars + 0, c->d_rd_chunk, chunk_first, chunk_mul, c->d_key_base, c->cfg.k, c->cfg.hb,
                        c->d_words[0], c->cfg.max_batch_keys, c->d_err); }
   HIPCHK(hipGetLastError());
   return SHK_OK;
@@ -347,12 +344,14 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
 
 // words in d_words[src] (count in d_scalars[1], bound nmax) -> sorted by region in
 // d_words[*dst]; region offsets in d_base[nlevels]
-static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
+// (ext != null: the first level reads the caller's buffer instead of d_words[src])
+static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr) {
   const uint64_t *n_p = c->d_scalars + 1;
   { ProfScope ps(c, KP_RP_PREP);
     hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]); }
   const uint32_t nwin = (uint32_t)(nmax / SHK_RP_TILE + 1);
-  int cur = src;
+  const uint64_t *in = ext ? ext : c->d_words[src];
+  int cur = ext ? 1 : src;   // the buffer `in` occupies (an external source leaves both free: write to d_words[0] first)
   for (uint32_t l = 0; l < c->nlevels; l++) {
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
     { ProfScope ps(c, KP_RP_PREP);
@@ -360,13 +359,14 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst) {
       HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
     { ProfScope ps(c, KP_RP_HIST);
       const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
-      hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, c->d_words[cur], n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
+      hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
     if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
     HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
     { ProfScope ps(c, KP_RP_SCATTER);
-      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[cur], c->d_words[cur ^ 1], n_p,
+      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
                          c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor, c->d_err); }
     cur ^= 1;
+    in = c->d_words[cur];
   }
   if (c->nlevels == 0) {
     // a single region: its keys are [0, n)
@@ -415,6 +415,11 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
   spill = spill && c->use_spill;
   c->spill_valid = 0;
+  if (want_hist == 2 && !c->d_newchunks && !getenv("SHK_COARSE_HIST")) {
+    // first request for the exact histogram (contexts that never reach a deNoise point never pay for it)
+    if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
+    HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
+  }
   const bool exact = want_hist == 2 && c->d_newchunks;
   if (exact) A.newchunks = c->d_newchunks;
   o->have_chist = 0;
@@ -768,7 +773,7 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   shk_batch_stats st;
   memset(&st, 0, sizeof(st));
   HIPCHK(hipSetDevice(c->dev));
-  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0);
+  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1);
   if (rc) return finish(c, rc);
   uint32_t bits = 0;
   HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -789,7 +794,7 @@ extern "C" int shk_hash_chunks(shk_ctx *c, const void *text, int text_on_device,
                                uint64_t **d_words, uint64_t *nwords) {
   if (!c || !text || !d_words || !nwords) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
-  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0);
+  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, c->cfg.shard_index, c->cfg.num_shards ? c->cfg.num_shards : 1);
   if (rc) return finish(c, rc);
   HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
   rc = finish(c, 0);
@@ -805,12 +810,13 @@ extern "C" int shk_count_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwo
   shk_batch_stats st;
   memset(&st, 0, sizeof(st));
   HIPCHK(hipSetDevice(c->dev));
-  if (d_words != c->d_words[0] && nwords)
-    HIPCHK(hipMemcpyAsync(c->d_words[0], d_words, nwords * 8, hipMemcpyDeviceToDevice, c->stream));
   c->h_pinned[43] = nwords;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
   int dst = 0;
-  int rc = partition_stage(c, 0, nwords, &dst);
+  // the first partition level reads the caller's buffer in place (no staging copy)
+  int rc = d_words == c->d_words[0] ? partition_stage(c, 0, nwords, &dst)
+         : d_words == c->d_words[1] ? partition_stage(c, 1, nwords, &dst)
+                                    : partition_stage(c, 0, nwords, &dst, d_words);
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
@@ -863,12 +869,13 @@ extern "C" int shk_stage_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwo
   if (!c || (!d_words && nwords)) return SHK_ERR_ARG;
   if (nwords > c->cfg.max_batch_keys) return SHK_ERR_BATCH;
   HIPCHK(hipSetDevice(c->dev));
-  if (d_words != c->d_words[0] && nwords)
-    HIPCHK(hipMemcpyAsync(c->d_words[0], d_words, nwords * 8, hipMemcpyDeviceToDevice, c->stream));
   c->h_pinned[43] = nwords;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
   int dst = 0;
-  int rc = partition_stage(c, 0, nwords, &dst);
+  // the first partition level reads the caller's buffer in place (no staging copy)
+  int rc = d_words == c->d_words[0] ? partition_stage(c, 0, nwords, &dst)
+         : d_words == c->d_words[1] ? partition_stage(c, 1, nwords, &dst)
+                                    : partition_stage(c, 0, nwords, &dst, d_words);
   c->staged = dst;
   return finish(c, rc);
 }

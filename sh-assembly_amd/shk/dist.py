@@ -179,17 +179,12 @@ def wrap_words(ptr, n, device):
 
 
 def route_words(ctx, nwords, hb, world, rank, device):
-    """Exchange the key words shk_hash_chunks left in the context: chunk indices become global
-    (the ranks' parts interleave like the reference's file queue, cqf/CQF_mt.h:828-830), the library
-    bins them by owner (shk_route_words), and the bins travel in all-to-alls of at most ROUTE_PIECE
-    words per peer (one RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only
-    its first 832 MB on this stack; bounded pieces also bound the staging memory)."""
-    dp0 = ctx.words_ptr()
-    words = wrap_words(dp0, nwords, device)
-    if nwords:
-        words.copy_((words & ((1 << hb) - 1)) | (((words >> hb) * world + rank) << hb))
-    if device.type == "cuda":
-        torch.cuda.synchronize()
+    """Exchange the key words shk_hash_chunks left in the context (their chunk indices are already
+    global: a sharded context labels chunk i as i * world + rank, so the ranks' parts interleave like
+    the reference's file queue, cqf/CQF_mt.h:828-830): the library bins them by owner
+    (shk_route_words), and the bins travel in all-to-alls of at most ROUTE_PIECE words per peer (one
+    RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only its first 832 MB on this
+    stack; bounded pieces also bound the staging memory)."""
     dp, sc = ctx.route_words(nwords, world)
     send = wrap_words(dp, nwords, device)
     send_counts = torch.tensor(sc, dtype=torch.int64, device=device)
