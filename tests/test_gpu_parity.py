@@ -239,3 +239,46 @@ def test_large_scale_properties(tmp_path):
             ctx2.close()
         ctx.close()
     assert digests[0] == digests[1]
+
+
+def test_sharded_flow_one_rank_matches_oracle():
+    """The multi-GPU flow (hash -> route -> all-to-all -> stage -> collective try/accept, shk/dist.py) with
+    one rank over RCCL: one shard is the whole filter, so the table must equal the oracle's byte for byte,
+    deNoise rounds included."""
+    import torch
+    import torch.distributed as dist
+    from shk import dist as shkdist
+    qb, k, trigger, nd, ml = 16, 31, 12000, 3, 1 << 11
+    g = synth.make_genome(12000, 5)
+    fq = synth.make_fastq(g, 2400, 100, 0.01, seed=33, n_frac=0.03, short_frac=0.02)
+    offs, lens = chunks_by_records(fq, 100)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        ctx = _ctx(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=1 << 20,
+                   shard_index=0, num_shards=1)
+        st = shkdist.ShardState(trigger, nd, dev)
+        rounds = removed = 0
+        third = len(offs) // 3
+        for a, b in ((0, third), (third, 2 * third), (2 * third, len(offs))):   # three batches
+            _, nw = ctx.hash_chunks(fq, offs[a:b], lens[a:b])
+            recv = shkdist.route_words(ctx, nw, qb + 8, 1, 0, dev)
+            ctx.stage_words(recv.data_ptr(), recv.numel())
+            out = shkdist.sharded_count(ctx, st, b - a)
+            rounds += out["denoise_rounds"]
+            removed += out["removed"]
+        q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, trigger, nd, False, ml)
+        assert not q.full()
+        assert (rounds, removed) == (orounds, oremoved) and rounds >= 1
+        t = ctx.totals()
+        assert (t.nelts, t.ndistinct) == (q.nelts(), q.ndistinct()) == (st.nelts, st.ndistinct)
+        assert ctx.blocks() == q.blocks()
+        ctx.close()
+        q.free()
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
