@@ -182,3 +182,21 @@ def test_long_cluster_retries_with_big_image(shk):
     cnt, _ = ctx.lookup(ks, mode=2)
     assert cnt == [small[k] for k in ks]
     ctx.close()
+
+
+@pytest.mark.parametrize("qb", [6, 8, 9])
+def test_tiny_filters_single_region(shk, qb):
+    """filters of one or two regions (no partition digits at all for qb <= 8): the last partition level
+    still converts the key words to the rebuild kernel's 32-bit records"""
+    fq = synth.make_fastq(synth.make_genome(60, 3), 4, 40, 0.0, seed=2)
+    offs, lens = chunks_by_records(fq, 2)
+    k = 28
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    assert not q.full()
+    ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=1 << 16, max_batch_keys=1 << 12)
+    ctx.count_chunks(fq, offs, lens)
+    t = ctx.totals()
+    assert (t.nelts, t.ndistinct) == (q.nelts(), q.ndistinct())
+    assert ctx.blocks() == q.blocks()
+    ctx.close()
+    q.free()
