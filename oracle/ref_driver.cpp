@@ -26,6 +26,9 @@
 #include <string>
 #include <vector>
 #include <deque>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 #include "cqf/gqf.h"        // -I/root/reference
 #include "base/nthash.hpp"  // -I/root/reference
@@ -191,7 +194,10 @@ uint64_t ref_denoise_round_t1(RefQF *h, uint64_t min_len) {
 // ---------------------------------------------------------------- reads_to_kmers
 // restates cqf/CQF_mt.h:610-731 for one thread (the try-lock never fails with one
 // thread, so the local-QF fallback at :639-645 is unreachable).
-void ref_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksize) {
+// spin = false is the reference's own call (one thread never finds a region lock busy); the timing entry below
+// runs several threads and lets them wait for the lock instead of diverting to a thread-local filter
+static void rd_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksize, bool spin, uint64_t *new_out,
+                              uint64_t *total_out) {
   uint64_t new_elts = 0, total_elts = 0;
   bool isNew;
   QF *main_qf = &h->qf;
@@ -210,7 +216,7 @@ void ref_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksi
       NTPC64(read.c_str(), ksize, hash, hash_RC);
       {
         uint64_t hv = hash < hash_RC ? hash : hash_RC;
-        qf_insert_advance(main_qf, (uint64_t)(hv % main_qf->metadata->range), 0, 1, true, false, isNew);
+        qf_insert_advance(main_qf, (uint64_t)(hv % main_qf->metadata->range), 0, 1, true, spin, isNew);
         if (isNew) new_elts++; else total_elts++;
       }
       for (uint32_t i = ksize; i < read.length(); i++) {
@@ -220,7 +226,7 @@ void ref_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksi
         }
         NTPC64(read[i - ksize], read[i], ksize, hash, hash_RC);
         uint64_t hv = hash < hash_RC ? hash : hash_RC;
-        qf_insert_advance(main_qf, (uint64_t)(hv % main_qf->metadata->range), 0, 1, true, false, isNew);
+        qf_insert_advance(main_qf, (uint64_t)(hv % main_qf->metadata->range), 0, 1, true, spin, isNew);
         if (isNew) new_elts++; else total_elts++;
       }
     }
@@ -231,8 +237,44 @@ void ref_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksi
     fs = static_cast<const char *>(memchr(fs, '\n', end - fs));
     fs++;
   }
-  h->ndistinct += new_elts;
-  h->nelts += (new_elts + total_elts);
+  *new_out = new_elts;
+  *total_out = new_elts + total_elts;
+}
+void ref_reads_to_kmers(RefQF *h, const char *chunk, uint64_t size, unsigned ksize) {
+  uint64_t nw = 0, tot = 0;
+  rd_reads_to_kmers(h, chunk, size, ksize, false, &nw, &tot);
+  h->ndistinct += nw;
+  h->nelts += tot;
+}
+
+// CPU baseline for bench.py: `nthreads` threads take chunks from a shared cursor and insert into the
+// one filter under the reference's region locks (what CQF_mt does with -t N, CQF_mt.h:821-831, minus
+// the thread-local overflow filter). Stops taking chunks after `budget_s` seconds. Returns seconds.
+double ref_time_chunks_mt(RefQF *h, const char *text, const uint64_t *offs, const uint64_t *lens, uint32_t nchunks,
+                          unsigned ksize, unsigned nthreads, double budget_s, uint64_t *kmers_out, uint32_t *chunks_out) {
+  std::atomic<uint32_t> next(0);
+  std::atomic<uint64_t> kmers(0), newk(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nthreads; t++)
+    th.emplace_back([&]() {
+      for (;;) {
+        if (elapsed() > budget_s) break;
+        uint32_t c = next.fetch_add(1);
+        if (c >= nchunks) break;
+        uint64_t nw = 0, tot = 0;
+        rd_reads_to_kmers(h, text + offs[c], lens[c], ksize, true, &nw, &tot);
+        kmers += tot; newk += nw;
+      }
+    });
+  for (auto &x : th) x.join();
+  double dt = elapsed();
+  h->nelts += kmers; h->ndistinct += newk;
+  *kmers_out = kmers;
+  uint32_t used = next.load();
+  *chunks_out = used < nchunks ? used : nchunks;
+  return dt;
 }
 
 // ---------------------------------------------------------------- chunker

@@ -71,6 +71,15 @@ class _QF:
     def reads_to_kmers(self, chunk: bytes, k):
         self._f("reads_to_kmers")(self.h, chunk, len(chunk), k)
 
+    def time_chunks_mt(self, text: bytes, offs, lens, k, nthreads, budget_s):
+        """(seconds, k-mers inserted, chunks taken): `nthreads` threads insert under the reference's region locks"""
+        n = len(offs)
+        o = (C.c_uint64 * n)(*offs)
+        ln = (C.c_uint64 * n)(*lens)
+        km, ch = C.c_uint64(), C.c_uint32()
+        dt = self._f("time_chunks_mt")(self.h, text, o, ln, n, k, nthreads, budget_s, C.byref(km), C.byref(ch))
+        return dt, km.value, ch.value
+
     def find_first_empty_slot(self, frm):
         return getattr(self.L, self.p + "find_first_empty_slot")(self.h, frm)
 
@@ -130,6 +139,9 @@ class _Lib:
                                u64, u32, u64, C.POINTER(u64)])
         if p == "ref_":
             sig("encode_counter", i32, [vp, u64, u64, C.POINTER(u64)])
+            if hasattr(L, "ref_time_chunks_mt"):   # (a prebuilt oracle/_ref from before this entry existed lacks it)
+                sig("time_chunks_mt", C.c_double, [vp, C.c_char_p, C.POINTER(u64), C.POINTER(u64), u32, C.c_uint, C.c_uint,
+                                                   C.c_double, C.POINTER(u64), C.POINTER(u32)])
         else:
             sig("encode_counter", i32, [u64, u64, C.POINTER(u64)])
             sig("chunk_keys", u64, [C.c_char_p, u64, C.c_uint, u64, C.POINTER(u64), u64])
