@@ -20,7 +20,9 @@
 #define SHK_EMPTY 0xFFFFFFFFu
 #define SHK_SUM_STRIDE 8
 #define SHK_SPILL_LENS SHK_REGION                                   // one length byte per quotient
-#define SHK_SPILL_STRIDE (SHK_SPILL_LENS + SHK_WAVE * 40)          // + the lanes' staged run bytes, packed
+#define SHK_SPILL_STRIDE 1024                                        // + the lanes' staged run bytes, packed: a filled region needs
+                                                                     // about 200; one that needs more than the record holds is rebuilt from the list
+#define SHK_SPILL_PACK_MAX (SHK_SPILL_STRIDE - SHK_SPILL_LENS)
 #define SHK_RSCAN_TILE 4096
 
 struct ShkMergeArgs {
@@ -192,6 +194,7 @@ __device__ __forceinline__ void shk_store_image(const ShkMergeArgs &A, uint32_t 
 // and encodings for k_region_place. MODE 2: single launch -- the wave obtains its
 // free pointer by looking back at the regions before it (see k_region_merge docs below).
 #define SHK_STAGE_PER_LANE 40   // bytes of encoded run kept per lane between the length pass and placement
+#define SHK_STAGE_STRIDE 44     // lanes 11 dwords apart: byte i of every lane's area falls into a different LDS bank
 #define SHK_LB_VALID 0x80000000u
 #define SHK_LB_INCL (1ULL << 63)
 
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ uint16_t rstart[SHK_REGION];
   __shared__ __attribute__((aligned(16))) uint8_t oimg[IMG_BYTES + 16];
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
-  __shared__ __attribute__((aligned(16))) uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_PER_LANE];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[SHK_MERGE_THREADS * SHK_STAGE_STRIDE];
   __shared__ uint64_t oocc[SHK_REGION_BLOCKS];
   __shared__ uint64_t orunw[IMG_BLOCKS];
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
@@ -431,7 +434,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
   uint32_t st_used = 0;            // staged bytes of this lane
   bool st_over = false;            // a run did not fit: this lane re-merges at placement time
-  uint8_t *mystage = stage + tid * SHK_STAGE_PER_LANE;
+  uint8_t *mystage = stage + tid * SHK_STAGE_STRIDE;
   // The lane's four quotients are merged in ONE loop over (quotient, remainder) order: the old entries
   // of its runs on one side, its new keys (nidx is sorted the same way) on the other. A wave runs the
   // loop as often as its busiest lane has entries -- about half of what four per-quotient loops cost.
@@ -597,13 +600,15 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       l4 |= (len & 255u) << (8 * j);
     }
     reinterpret_cast<uint32_t *>(sp)[tid] = l4;
-    const bool over = !fatal && __ballot(big) != 0;
+    const uint32_t sincl = shk_wave_incl_add(st_used);
+    const uint32_t stot = __shfl(sincl, SHK_WAVE - 1);
+    const bool over = !fatal && (__ballot(big) != 0 || stot > SHK_SPILL_PACK_MAX);
     if (tid == 0) {
       A.summary[(size_t)SHK_SUM_STRIDE * r + 6] = over ? 1 : 0;
       if (over) A.over_list[atomicAdd(A.n_over, 1ULL)] = r;
     }
     if (!over) {
-      const uint32_t ex = shk_wave_incl_add(st_used) - st_used;
+      const uint32_t ex = sincl - st_used;
       for (uint32_t i = 0; i < st_used; i++) sp[SHK_SPILL_LENS + ex + i] = mystage[i];
     }
     return;
@@ -798,7 +803,7 @@ template <int IMGB>
 __global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
   constexpr unsigned IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
-  __shared__ __attribute__((aligned(16))) uint8_t pack[SHK_WAVE * 40];
+  __shared__ __attribute__((aligned(16))) uint8_t pack[SHK_SPILL_PACK_MAX];
   const unsigned tid = threadIdx.x;
   const uint32_t r = blockIdx.x;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
