@@ -3,6 +3,7 @@
 
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local EmuBlock *emu_block;
+thread_local unsigned emu_phase;
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()> &body) {
   const unsigned nthr = block.x, nw = (nthr + 63) / 64;
@@ -20,6 +21,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()> &body) {
       ths.emplace_back([=, &body]() {
         threadIdx = dim3(t); blockIdx = dim3(b); blockDim = block; gridDim = grid;
         emu_block = eb;
+        emu_phase = 0;
         body();
         eb->bar->arrive_and_drop();
       });

@@ -47,7 +47,10 @@ enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 enum { hipHostMallocDefault = 0 };
 
-struct EmuWave { pthread_barrier_t bar; uint64_t box[64]; };
+// two mailboxes used alternately: one barrier per collective is enough (a lane can only overwrite a box two
+// collectives later, i.e. after a barrier every reader of that box has already passed)
+struct EmuWave { pthread_barrier_t bar; uint64_t box[2][64]; };
+extern thread_local unsigned emu_phase;
 // the workgroup barrier drops threads that have left the kernel (waves may exit early on the GPU too)
 struct EmuBlock { std::barrier<> *bar; EmuWave waves[16]; };
 extern thread_local EmuBlock *emu_block;
@@ -69,10 +72,10 @@ template <typename T> static inline T emu_xchg(T v, int src_lane, bool valid) {
   EmuWave *w = emu_wave();
   uint64_t raw = 0;
   memcpy(&raw, &v, sizeof(T));
-  w->box[threadIdx.x & 63] = raw;
+  const unsigned ph = emu_phase++ & 1;
+  w->box[ph][threadIdx.x & 63] = raw;
   pthread_barrier_wait(&w->bar);
-  uint64_t got = valid ? w->box[src_lane & 63] : raw;
-  pthread_barrier_wait(&w->bar);
+  uint64_t got = valid ? w->box[ph][src_lane & 63] : raw;
   T out;
   memcpy(&out, &got, sizeof(T));
   return out;
@@ -104,11 +107,11 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_xchg(v, lane, true); }
 static inline unsigned long long __ballot(int pred) {
   EmuWave *w = emu_wave();
-  w->box[threadIdx.x & 63] = pred ? 1 : 0;
+  const unsigned ph = emu_phase++ & 1;
+  w->box[ph][threadIdx.x & 63] = pred ? 1 : 0;
   pthread_barrier_wait(&w->bar);
   unsigned long long m = 0;
-  for (int i = 0; i < 64; i++) m |= (unsigned long long)(w->box[i] & 1) << i;
-  pthread_barrier_wait(&w->bar);
+  for (int i = 0; i < 64; i++) m |= (unsigned long long)(w->box[ph][i] & 1) << i;
   return m;
 }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }

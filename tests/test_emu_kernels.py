@@ -54,9 +54,9 @@ def test_key_stream_is_reference_order(shk):
 def test_count_and_denoise_schedule(shk):
     """hash -> partition (several levels forced) -> merge -> deNoise rounds where the t = 1 schedule
     fires them; table bytes, header and counters equal the oracle's"""
-    fq = synth.make_fastq(synth.make_genome(300, 7), 48, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
-    offs, lens = chunks_by_records(fq, 5)
-    qb, k, trig, nd, ml = 11, 28, 600, 3, 64
+    fq = synth.make_fastq(synth.make_genome(300, 7), 32, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
+    offs, lens = chunks_by_records(fq, 4)
+    qb, k, trig, nd, ml = 10, 28, 350, 3, 64
     ctx = _ctx(shk, qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=1 << 20,
                max_batch_keys=1 << 16, max_level_bits=2)
     half = len(offs) // 2
