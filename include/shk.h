@@ -16,6 +16,9 @@
  *   shk_import_cqf        CQF_mt::load -> qf_deserialize                   cqf/CQF_mt.h:514-519; gqf.c:2396-2420
  *   shk_lookup            qf_count_key_value /
  *                         qf_count_key_value_{is,set}_traveled             cqf/gqf.c:2442-2469, 3092-3163
+ *   shk_extend_forward    get_unitig_forward, the walk that meets no other
+ *                         unitig (Contiger, first slice)                   src/contig_assembly.cpp:3028-3218
+ *   shk_unitigs_from_seeds its two calls per seed + median abundance        src/contig_assembly.cpp:1886-1904; base/Utility.cpp:27-40
  *   shk_stats             runtime->nelts / ndistinct_elts / num_deNoise    cqf/CQF_mt.h:277-288
  *   shk_destroy           CQF_mt::~CQF_mt -> qf_destroy                    cqf/CQF_mt.h:547-557; gqf.c:2306
  *
@@ -167,6 +170,29 @@ int shk_import_blocks(shk_ctx *ctx, const void *host_src, uint64_t nbytes, uint6
  * keys/counts/was_traveled are host pointers unless on_device != 0. was_traveled may be NULL. */
 int shk_lookup(shk_ctx *ctx, const uint64_t *keys, uint64_t n, int on_device, int mode,
                uint64_t *counts, uint8_t *was_traveled);
+
+/* ---- Contiger, first slice: forward extension of many open unitig ends at once.
+ * For end i: cur_kmers[i*k ..] is the contig's last k-mer, first_kmers[i*k ..] its first (upper-case ACGT). Per
+ * step the kernel looks up the 4 successors and the 3 siblings of the current k-mer and applies the reference's
+ * rule (stop on a solid sibling or > 1 solid successor; extend on exactly one; stop on none or on a pure
+ * circle), for a walk that meets no other unitig (no startKmer2unitig hits). out_bases/out_counts hold up to
+ * max_ext appended bases and the filter counts of the k-mers they complete, out_n their number, out_stop why
+ * the walk ended (SHK_STOP_*). mark_traveled != 0 sets the traveled bit of every k-mer looked up, as the
+ * reference's count_key_value_set_traveled does. k <= 64. All pointers are host pointers. */
+#define SHK_STOP_BRANCH 1
+#define SHK_STOP_DEAD_END 2
+#define SHK_STOP_CIRCLE 3
+#define SHK_STOP_BUFFER 4
+#define SHK_STOP_BAD_SEED 5
+int shk_extend_forward(shk_ctx *ctx, const char *cur_kmers, const char *first_kmers, uint32_t n, uint32_t k,
+                       uint64_t abundance_min, int mark_traveled, uint32_t max_ext, char *out_bases,
+                       uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop);
+/* One maximal unitig per seed k-mer: extend, reverse-complement, extend again; out_seq[i*max_len ..] holds
+ * out_len[i] bases, out_median[i] the contig's median abundance as the reference stores it (int),
+ * out_stop[2*i], out_stop[2*i+1] the two stop reasons. seed_counts[i] = the seed's filter count. */
+int shk_unitigs_from_seeds(shk_ctx *ctx, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
+                           uint64_t abundance_min, uint32_t max_len, char *out_seq, uint32_t *out_len,
+                           int32_t *out_median, uint8_t *out_stop);
 
 /* per-kernel device time measured with HIP events on the context's stream */
 typedef struct shk_kernel_time {

@@ -56,6 +56,12 @@ uint64_t orc_qf_ndistinct(const orc_qf *qf);
 int orc_qf_full(const orc_qf *qf);
 void orc_qf_header(const orc_qf *qf, uint8_t out[128]);                /* qfmetadata image, gqf.h:62-77 */
 
+/* Contiger's unitig extension, first slice (contiger_oracle.c; parity unpinned, see its header) */
+int orc_extend_forward(const orc_qf *qf, char *seq, uint32_t *len, unsigned k, uint64_t abundance_min, uint32_t max_len,
+                       int *median);                                    /* src/contig_assembly.cpp:3028-3218 */
+int orc_unitig_from_seed(const orc_qf *qf, const char *seed, uint32_t seed_count, unsigned k, uint64_t abundance_min,
+                         uint32_t max_len, char *seq, uint32_t *len, int *median, uint8_t stops[2]); /* :1886-1904 */
+
 /* driver layer, cqf/CQF_mt.h */
 void orc_reads_to_kmers(orc_qf *qf, const char *chunk, uint64_t size, unsigned k); /* :610-731 */
 uint64_t orc_chunk_sizes(const char *path, uint64_t part_size, uint32_t overhead,

@@ -1128,11 +1128,9 @@ __global__ void k_denoise_marks(uint8_t *tab, uint64_t nslots, uint64_t xnslots,
 // one thread per query. The traveled bit belongs to the first slot of the entry; it is set
 // with a 32-bit atomic OR on the aligned word holding that bit (the reference uses a
 // plain, racy |=, gqf.c:3078).
-__global__ void k_lookup(uint8_t *tab, const uint64_t *keys, uint64_t n, uint64_t q_lo, uint64_t nslots, int mark,
-                         uint64_t *counts, uint8_t *was_traveled) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
+// mark: 0 read the traveled bit, 1 set it and return the previous value, 2 leave it alone
+__device__ __forceinline__ uint64_t shk_lookup_one(uint8_t *tab, uint64_t key, uint64_t q_lo, uint64_t nslots, int mark,
+                                                   uint8_t *trav_out) {
   const unsigned rem = key & 0xff;
   const uint64_t q = (key >> 8) - q_lo;
   uint64_t cnt = 0;
@@ -1174,7 +1172,16 @@ __global__ void k_lookup(uint8_t *tab, const uint64_t *keys, uint64_t n, uint64_
       rs = e + 1;
     }
   }
-  counts[i] = cnt;
+  *trav_out = trav;
+  return cnt;
+}
+
+__global__ void k_lookup(uint8_t *tab, const uint64_t *keys, uint64_t n, uint64_t q_lo, uint64_t nslots, int mark,
+                         uint64_t *counts, uint8_t *was_traveled) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t trav = 0;
+  counts[i] = shk_lookup_one(tab, keys[i], q_lo, nslots, mark, &trav);
   if (was_traveled) was_traveled[i] = trav;
 }
 

@@ -10,21 +10,24 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <string>
+#include <algorithm>
 
 #include "kmer_kernels.hip"
 #include "partition_kernels.hip"
 #include "cqf_kernels.hip"
+#include "walk_kernels.hip"
 
 #define SHK_SLACK 256  // bytes of slack behind buffers read with wide loads
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -1062,6 +1065,90 @@ extern "C" int shk_lookup(shk_ctx *c, const uint64_t *keys, uint64_t n, int on_d
     hipFree(dk); hipFree(dc); hipFree(dt);
   }
   return finish(c, 0);
+}
+
+// ------------------------------------------------------------------ Contiger: unitig extension (first slice)
+extern "C" int shk_extend_forward(shk_ctx *c, const char *cur_kmers, const char *first_kmers, uint32_t n, uint32_t k,
+                                  uint64_t abundance_min, int mark_traveled, uint32_t max_ext, char *out_bases,
+                                  uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop) {
+  if (!c || (n && (!cur_kmers || !first_kmers || !out_bases || !out_counts || !out_n || !out_stop))) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K || max_ext == 0) return SHK_ERR_ARG;
+  if (n == 0) return SHK_OK;
+  HIPCHK(hipSetDevice(c->dev));
+  char *dk = nullptr, *df = nullptr, *db = nullptr;
+  uint32_t *dc = nullptr, *dn = nullptr;
+  uint8_t *ds = nullptr;
+  const size_t nk = (size_t)n * k, ne = (size_t)n * max_ext;
+  if (dmalloc(&dk, nk) || dmalloc(&df, nk) || dmalloc(&db, ne) || dmalloc(&dc, ne) || dmalloc(&dn, (size_t)n) || dmalloc(&ds, (size_t)n))
+    return SHK_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(dk, cur_kmers, nk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(df, first_kmers, nk, hipMemcpyHostToDevice, c->stream));
+  { ProfScope ps(c, KP_WALK);
+    hipLaunchKernelGGL(k_extend_forward, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
+                       c->cfg.hb, dk, df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, db, dc, dn, ds); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_bases, db, ne, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_counts, dc, ne * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_n, dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_stop, ds, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipFree(dk); hipFree(df); hipFree(db); hipFree(dc); hipFree(dn); hipFree(ds);
+  return finish(c, 0);
+}
+
+// median() of base/Utility.cpp:27-40 stored into Contig::median_abundance, an int (truncation)
+static int walk_median(std::vector<int> &v) {
+  if (v.empty()) return 0;
+  if (v.size() == 1) return v[0];
+  std::sort(v.begin(), v.end());
+  const size_t t = v.size() / 2;
+  return v.size() % 2 == 0 ? (int)((v[t - 1] + v[t]) / 2.0) : v[t];
+}
+
+// One maximal unitig per seed k-mer: extend forward, reverse-complement, extend forward again -- the two
+// get_unitig_forward calls of processDataChunk (contig_assembly.cpp:1886-1904) in the case where no
+// other unitig is met. seeds: n * k upper-case bases; seed_counts: their filter counts (Contig(kmer, count)).
+extern "C" int shk_unitigs_from_seeds(shk_ctx *c, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
+                                      uint64_t abundance_min, uint32_t max_len, char *out_seq, uint32_t *out_len,
+                                      int32_t *out_median, uint8_t *out_stop) {
+  if (!c || (n && (!seeds || !seed_counts || !out_seq || !out_len || !out_median || !out_stop))) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
+  const uint32_t max_ext = max_len - k;
+  std::vector<std::string> seq(n);
+  std::vector<int> med(n);
+  for (uint32_t i = 0; i < n; i++) { seq[i].assign(seeds + (size_t)i * k, k); med[i] = (int)seed_counts[i]; }
+  std::vector<char> cur((size_t)n * k), first((size_t)n * k), ext((size_t)n * max_ext);
+  std::vector<uint32_t> cnt((size_t)n * max_ext), en(n);
+  std::vector<uint8_t> st(n);
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t i = 0; i < n; i++) {
+      memcpy(&first[(size_t)i * k], seq[i].data(), k);
+      memcpy(&cur[(size_t)i * k], seq[i].data() + seq[i].size() - k, k);
+    }
+    int rc = shk_extend_forward(c, cur.data(), first.data(), n, k, abundance_min, 0, max_ext, ext.data(), cnt.data(), en.data(), st.data());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+      // abundances start as (length - K + 1) copies of the contig's current median (contig_assembly.cpp:3049)
+      std::vector<int> ab(seq[i].size() - k + 1, med[i]);
+      uint32_t take = en[i];
+      if (seq[i].size() + take > max_len) { take = max_len - (uint32_t)seq[i].size(); st[i] = SHK_STOP_BUFFER; }
+      for (uint32_t j = 0; j < take; j++) ab.push_back((int)cnt[(size_t)i * max_ext + j]);
+      seq[i].append(&ext[(size_t)i * max_ext], take);
+      med[i] = walk_median(ab);
+      out_stop[(size_t)i * 2 + pass] = st[i];
+      if (pass == 0) {   // DNAString::RC
+        std::string r(seq[i].rbegin(), seq[i].rend());
+        for (auto &ch : r) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+        seq[i].swap(r);
+      }
+    }
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    memcpy(out_seq + (size_t)i * max_len, seq[i].data(), seq[i].size());
+    out_len[i] = (uint32_t)seq[i].size();
+    out_median[i] = med[i];
+  }
+  return SHK_OK;
 }
 
 extern "C" int shk_profile_enable(shk_ctx *c, int on) { if (!c) return SHK_ERR_ARG; c->prof_on = on; return SHK_OK; }

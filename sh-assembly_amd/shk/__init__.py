@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_denoise",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
            "shk_last_error_bits"]
@@ -90,6 +90,10 @@ def load(path=None):
     L.shk_stage_try.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
     L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
     L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
+    L.shk_extend_forward.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32, u64, i32, u32, C.c_char_p, C.POINTER(u32),
+                                     C.POINTER(u32), C.POINTER(C.c_uint8)]
+    L.shk_unitigs_from_seeds.argtypes = [vp, C.c_char_p, C.POINTER(u32), u32, u32, u64, u32, C.c_char_p, C.POINTER(u32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_uint8)]
     L.shk_denoise.argtypes = [vp, pu64]
     L.shk_stats.argtypes = [vp, C.POINTER(Totals)]
     L.shk_header.argtypes = [vp, C.c_char_p]
@@ -212,6 +216,18 @@ class Context:
         if self.L.shk_stage_chunk_hist(self.h, out, n) != 0:
             return None
         return [out[i] for i in range(n)]
+
+    def unitigs_from_seeds(self, seeds, seed_counts, k, abundance_min, max_len):
+        """[(sequence, median abundance, (stop1, stop2))] -- one maximal unitig per seed k-mer (bytes of length k)"""
+        n = len(seeds)
+        sc = (C.c_uint32 * max(n, 1))(*seed_counts)
+        out = C.create_string_buffer(max(n, 1) * max_len)
+        ln = (C.c_uint32 * max(n, 1))()
+        md = (C.c_int32 * max(n, 1))()
+        st = (C.c_uint8 * (2 * max(n, 1)))()
+        self._chk(self.L.shk_unitigs_from_seeds(self.h, b"".join(seeds), sc, n, k, abundance_min, max_len, out, ln, md, st))
+        raw = out.raw
+        return [(raw[i * max_len:i * max_len + ln[i]], md[i], (st[2 * i], st[2 * i + 1])) for i in range(n)]
 
     def stage_accept(self, summary):
         self._chk(self.L.shk_stage_accept(self.h, C.byref(summary)))

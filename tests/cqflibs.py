@@ -71,6 +71,15 @@ class _QF:
     def reads_to_kmers(self, chunk: bytes, k):
         self._f("reads_to_kmers")(self.h, chunk, len(chunk), k)
 
+    def unitig_from_seed(self, seed: bytes, seed_count, k, abundance_min, max_len):
+        """(sequence, median abundance, (stop1, stop2)): Contiger's two extensions of one seed (oracle only)"""
+        out = C.create_string_buffer(max_len + 1)
+        ln, md = C.c_uint32(), C.c_int()
+        st = (C.c_uint8 * 2)()
+        rc = self._f("unitig_from_seed")(self.h, seed, seed_count, k, abundance_min, max_len, out, C.byref(ln), C.byref(md), st)
+        assert rc == 0
+        return out.raw[:ln.value], md.value, (st[0], st[1])
+
     def time_chunks_mt(self, text: bytes, offs, lens, k, nthreads, budget_s):
         """(seconds, k-mers inserted, chunks taken): `nthreads` threads insert under the reference's region locks"""
         n = len(offs)
@@ -137,6 +146,9 @@ class _Lib:
         sig("chunk_sizes", u64, [C.c_char_p, u64, u32, C.POINTER(u64), u64])
         sig("build_t1", None, [vp, C.POINTER(C.c_char_p), i32, C.c_uint, u64, u32, i32,
                                u64, u32, u64, C.POINTER(u64)])
+        if p == "orc_":
+            sig("unitig_from_seed", i32, [vp, C.c_char_p, u32, C.c_uint, u64, u32, C.c_char_p, C.POINTER(u32),
+                                          C.POINTER(i32), C.POINTER(C.c_uint8)])
         if p == "ref_":
             sig("encode_counter", i32, [vp, u64, u64, C.POINTER(u64)])
             if hasattr(L, "ref_time_chunks_mt"):   # (a prebuilt oracle/_ref from before this entry existed lacks it)

@@ -200,3 +200,50 @@ def test_tiny_filters_single_region(shk, qb):
     assert ctx.blocks() == q.blocks()
     ctx.close()
     q.free()
+
+
+def _unitig_case(shk_mod, ctx_factory, qb, k, G, nreads, L, err, nseeds):
+    """filter from synthetic reads; seeds = middle k-mers of the reads that pass Contiger's seed filter
+    (count in [2, 1e6], contig_assembly.cpp:1860-1876); device unitigs vs the oracle's restatement"""
+    g = synth.make_genome(G, 11)
+    fq = synth.make_fastq(g, nreads, L, err, seed=13)
+    offs, lens = chunks_by_records(fq, max(1, nreads // 3))
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    assert not q.full()
+    ctx = ctx_factory(qb=qb, k=k, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L)
+    ctx.count_chunks(fq, offs, lens)
+    assert ctx.blocks() == q.blocks()
+    O = cqflibs.oracle()
+    hb = qb + 8
+    seeds, counts = [], []
+    for line in fq.split(b"\n")[1::4]:
+        if len(line) < k:
+            continue
+        mid = len(line) // 2 - k // 2
+        km = line[mid:mid + k].upper()
+        if b"N" in km or km in seeds:
+            continue
+        fh, rh = O.nthash(km, k)
+        c = q.count(min(fh, rh) & ((1 << hb) - 1))
+        if 2 <= c <= 1000000:
+            seeds.append(km)
+            counts.append(c)
+        if len(seeds) >= nseeds:
+            break
+    assert len(seeds) >= 3
+    max_len = 4 * G + k
+    got = ctx.unitigs_from_seeds(seeds, counts, k, 2, max_len)
+    stops = set()
+    for s, c, (seq, med, st) in zip(seeds, counts, got):
+        eseq, emed, est = q.unitig_from_seed(s, c, k, 2, max_len)
+        assert (seq, med, st) == (eseq, emed, est)
+        stops.update(st)
+        assert len(seq) >= k
+    ctx.close()
+    q.free()
+    return stops
+
+
+def test_unitig_extension_matches_oracle(shk):
+    stops = _unitig_case(shk, lambda **kw: _ctx(shk, **kw), qb=12, k=21, G=260, nreads=60, L=60, err=0.004, nseeds=6)
+    assert stops   # at least one stop reason seen

@@ -282,3 +282,13 @@ def test_sharded_flow_one_rank_matches_oracle():
     finally:
         if own_pg:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("qb,k,G,nreads,L,err,nseeds", [(17, 47, 20000, 2500, 150, 0.003, 300), (16, 31, 9000, 1500, 100, 0.01, 200)])
+def test_unitig_extension_matches_oracle(qb, k, G, nreads, L, err, nseeds):
+    """Contiger, first slice: maximal unitigs from seed k-mers (k_extend_forward, rolled hashes, one thread per
+    open end) against the oracle's restatement of get_unitig_forward (hashes from scratch)"""
+    import shk
+    from test_emu_kernels import _unitig_case
+    stops = _unitig_case(shk, lambda **kw: _ctx(**kw), qb=qb, k=k, G=G, nreads=nreads, L=L, err=err, nseeds=nseeds)
+    assert {1, 2} & stops      # branches (sequencing errors) or dead ends (genome ends) are met
