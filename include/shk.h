@@ -19,6 +19,8 @@
  *   shk_extend_forward    get_unitig_forward, the walk that meets no other
  *                         unitig (Contiger, first slice)                   src/contig_assembly.cpp:3028-3218
  *   shk_unitigs_from_seeds its two calls per seed + median abundance        src/contig_assembly.cpp:1886-1904; base/Utility.cpp:27-40
+ *   shk_find_unitigs      find_unitigs: seeds + work queue of branch
+ *                         neighbours + duplicate removal + writer (set-level) src/contig_assembly.cpp:3122-3160, 935-954, 606-626
  *   shk_stats             runtime->nelts / ndistinct_elts / num_deNoise    cqf/CQF_mt.h:277-288
  *   shk_destroy           CQF_mt::~CQF_mt -> qf_destroy                    cqf/CQF_mt.h:547-557; gqf.c:2306
  *
@@ -177,7 +179,8 @@ int shk_lookup(shk_ctx *ctx, const uint64_t *keys, uint64_t n, int on_device, in
  * rule (stop on a solid sibling or > 1 solid successor; extend on exactly one; stop on none or on a pure
  * circle), for a walk that meets no other unitig (no startKmer2unitig hits). out_bases/out_counts hold up to
  * max_ext appended bases and the filter counts of the k-mers they complete, out_n their number, out_stop why
- * the walk ended (SHK_STOP_*). mark_traveled != 0 sets the traveled bit of every k-mer looked up, as the
+ * the walk ended (SHK_STOP_*), out_branch (may be NULL) at a SHK_STOP_BRANCH the solid neighbours of the last
+ * k-mer s0 s1..s(k-1): bit x = successor s1..s(k-1)+x, bit 4+z = sibling z+s1..s(k-1) (x, z index "ACGT"); out_ncount (may be NULL, 8 per end) their filter counts. mark_traveled != 0 sets the traveled bit of every k-mer looked up, as the
  * reference's count_key_value_set_traveled does. k <= 64. All pointers are host pointers. */
 #define SHK_STOP_BRANCH 1
 #define SHK_STOP_DEAD_END 2
@@ -186,13 +189,27 @@ int shk_lookup(shk_ctx *ctx, const uint64_t *keys, uint64_t n, int on_device, in
 #define SHK_STOP_BAD_SEED 5
 int shk_extend_forward(shk_ctx *ctx, const char *cur_kmers, const char *first_kmers, uint32_t n, uint32_t k,
                        uint64_t abundance_min, int mark_traveled, uint32_t max_ext, char *out_bases,
-                       uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop);
+                       uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop, uint8_t *out_branch,
+                       uint32_t *out_ncount);
 /* One maximal unitig per seed k-mer: extend, reverse-complement, extend again; out_seq[i*max_len ..] holds
  * out_len[i] bases, out_median[i] the contig's median abundance as the reference stores it (int),
  * out_stop[2*i], out_stop[2*i+1] the two stop reasons. seed_counts[i] = the seed's filter count. */
 int shk_unitigs_from_seeds(shk_ctx *ctx, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
                            uint64_t abundance_min, uint32_t max_len, char *out_seq, uint32_t *out_len,
                            int32_t *out_median, uint8_t *out_stop);
+
+/* All unitigs reachable from the seeds, written as FASTA (`>i LN:i:len KC:i:median*(len-k+1) km:f:median`, the
+ * reference's record without the L: links of its graph pass): seeds are extended in both directions, every solid
+ * neighbour met at a branch starts a new contig (the reference's work queue), a unitig found more than once is
+ * kept once. The reference produces the same set of sequences up to reverse complement; ids and order are its
+ * thread schedule's and are not reproduced. */
+typedef struct shk_unitig_stats {
+  uint64_t unitigs, total_len;   /* kept unitigs and their summed length */
+  uint64_t rounds, extensions;   /* batched rounds; single forward extensions run on the device */
+  uint64_t duplicates, truncated;/* unitigs found again and dropped; walks cut at max_len */
+} shk_unitig_stats;
+int shk_find_unitigs(shk_ctx *ctx, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
+                     uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats);
 
 /* per-kernel device time measured with HIP events on the context's stream */
 typedef struct shk_kernel_time {

@@ -44,8 +44,10 @@ static int median_int(int *v, size_t n) {
 
 /* one get_unitig_forward: seq (length *len, capacity max_len) grows at its end; *median is the contig's
  * median_abundance on entry and on exit; returns the stop reason */
+/* branch (may be NULL): at a branch stop, bit x = solid successor fix+x, bit 4+z = solid sibling z+fix (x, z index
+ * DNA_bases); ncount (may be NULL, 8 entries): their filter counts -- the contigs the reference queues (:3133-3160) */
 int orc_extend_forward(const orc_qf *qf, char *seq, uint32_t *len, unsigned k, uint64_t abundance_min, uint32_t max_len,
-                       int *median) {
+                       int *median, uint8_t *branch, uint32_t *ncount) {
   char first[256], cur[256], cur_rc[256], kmer[256];
   if (k >= sizeof(first) || *len < k) return -1;
   memcpy(first, seq, k);
@@ -54,26 +56,36 @@ int orc_extend_forward(const orc_qf *qf, char *seq, uint32_t *len, unsigned k, u
   int *ab = (int *)malloc(cap * sizeof(int));
   for (size_t i = 0; i < nab; i++) ab[i] = *median;
   int stop = 0;
+  if (branch) *branch = 0;
+  if (ncount) memset(ncount, 0, 8 * sizeof(uint32_t));
   while (!stop) {
     memcpy(cur_rc, cur, k);
     rc_inplace(cur_rc, k);
     int cand_after = 0, cand_before = 0, xa = 0;
-    uint64_t count_after[4] = {0, 0, 0, 0};
+    uint64_t count_after[4] = {0, 0, 0, 0}, count_before[4] = {0, 0, 0, 0};
+    unsigned mask = 0;
     /* kmers with current_kmer_fix as prefix (:3067-3088) */
     memcpy(kmer, cur + 1, k - 1);
     for (int x = 0; x < 4; x++) {
       kmer[k - 1] = DNA_bases[x];
       uint64_t c = kmer_count(qf, kmer, k);
-      if (c >= abundance_min) { cand_after++; count_after[x] = c; xa = x; }
+      if (c >= abundance_min) { cand_after++; count_after[x] = c; xa = x; mask |= 1u << x; }
     }
     /* kmers with RC(current_kmer_fix) as prefix (:3090-3120), except the current k-mer itself */
     memcpy(kmer, cur_rc, k);
     for (int x = 0; x < 4; x++) {
       if (DNA_bases[x] == cur_rc[k - 1]) continue;
       kmer[k - 1] = DNA_bases[x];
-      if (kmer_count(qf, kmer, k) >= abundance_min) cand_before++;
+      uint64_t c = kmer_count(qf, kmer, k);
+      /* RC(fix)+x is the reverse complement of the sibling comp(x)+fix; comp(DNA_bases[x]) = DNA_bases[3-x] */
+      if (c >= abundance_min) { cand_before++; count_before[3 - x] = c; mask |= 16u << (3 - x); }
     }
-    if (cand_before || cand_after > 1) { stop = ORC_STOP_BRANCH; break; }   /* :3122 */
+    if (cand_before || cand_after > 1) {                                     /* :3122 */
+      stop = ORC_STOP_BRANCH;
+      if (branch) *branch = (uint8_t)mask;
+      if (ncount) for (int j = 0; j < 4; j++) { ncount[j] = (uint32_t)count_after[j]; ncount[4 + j] = (uint32_t)count_before[j]; }
+      break;
+    }
     if (cand_after == 0) { stop = ORC_STOP_DEAD_END; break; }               /* :3201 */
     memmove(cur, cur + 1, k - 1);                                            /* :3167-3190 */
     cur[k - 1] = DNA_bases[xa];
@@ -94,11 +106,11 @@ int orc_unitig_from_seed(const orc_qf *qf, const char *seed, uint32_t seed_count
   memcpy(seq, seed, k);
   *len = k;
   *median = (int)seed_count;
-  int s = orc_extend_forward(qf, seq, len, k, abundance_min, max_len, median);
+  int s = orc_extend_forward(qf, seq, len, k, abundance_min, max_len, median, NULL, NULL);
   if (s < 0) return s;
   stops[0] = (uint8_t)s;
   rc_inplace(seq, *len);
-  s = orc_extend_forward(qf, seq, len, k, abundance_min, max_len, median);
+  s = orc_extend_forward(qf, seq, len, k, abundance_min, max_len, median, NULL, NULL);
   if (s < 0) return s;
   stops[1] = (uint8_t)s;
   return 0;

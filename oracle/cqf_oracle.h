@@ -58,7 +58,7 @@ void orc_qf_header(const orc_qf *qf, uint8_t out[128]);                /* qfmeta
 
 /* Contiger's unitig extension, first slice (contiger_oracle.c; parity unpinned, see its header) */
 int orc_extend_forward(const orc_qf *qf, char *seq, uint32_t *len, unsigned k, uint64_t abundance_min, uint32_t max_len,
-                       int *median);                                    /* src/contig_assembly.cpp:3028-3218 */
+                       int *median, uint8_t *branch, uint32_t *ncount);                                    /* src/contig_assembly.cpp:3028-3218 */
 int orc_unitig_from_seed(const orc_qf *qf, const char *seed, uint32_t seed_count, unsigned k, uint64_t abundance_min,
                          uint32_t max_len, char *seq, uint32_t *len, int *median, uint8_t stops[2]); /* :1886-1904 */
 

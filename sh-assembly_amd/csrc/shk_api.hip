@@ -12,6 +12,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <unordered_set>
 
 #include "kmer_kernels.hip"
 #include "partition_kernels.hip"
@@ -1070,29 +1071,32 @@ extern "C" int shk_lookup(shk_ctx *c, const uint64_t *keys, uint64_t n, int on_d
 // ------------------------------------------------------------------ Contiger: unitig extension (first slice)
 extern "C" int shk_extend_forward(shk_ctx *c, const char *cur_kmers, const char *first_kmers, uint32_t n, uint32_t k,
                                   uint64_t abundance_min, int mark_traveled, uint32_t max_ext, char *out_bases,
-                                  uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop) {
+                                  uint32_t *out_counts, uint32_t *out_n, uint8_t *out_stop, uint8_t *out_branch,
+                                  uint32_t *out_ncount) {
   if (!c || (n && (!cur_kmers || !first_kmers || !out_bases || !out_counts || !out_n || !out_stop))) return SHK_ERR_ARG;
   if (k < 2 || k > SHK_WALK_MAX_K || max_ext == 0) return SHK_ERR_ARG;
   if (n == 0) return SHK_OK;
   HIPCHK(hipSetDevice(c->dev));
   char *dk = nullptr, *df = nullptr, *db = nullptr;
-  uint32_t *dc = nullptr, *dn = nullptr;
-  uint8_t *ds = nullptr;
+  uint32_t *dc = nullptr, *dn = nullptr, *dnc = nullptr;
+  uint8_t *ds = nullptr, *dbr = nullptr;
   const size_t nk = (size_t)n * k, ne = (size_t)n * max_ext;
-  if (dmalloc(&dk, nk) || dmalloc(&df, nk) || dmalloc(&db, ne) || dmalloc(&dc, ne) || dmalloc(&dn, (size_t)n) || dmalloc(&ds, (size_t)n))
+  if (dmalloc(&dk, nk) || dmalloc(&df, nk) || dmalloc(&db, ne) || dmalloc(&dc, ne) || dmalloc(&dn, (size_t)n) || dmalloc(&ds, (size_t)n) || dmalloc(&dbr, (size_t)n) || dmalloc(&dnc, (size_t)n * 8))
     return SHK_ERR_HIP;
   HIPCHK(hipMemcpyAsync(dk, cur_kmers, nk, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(df, first_kmers, nk, hipMemcpyHostToDevice, c->stream));
   { ProfScope ps(c, KP_WALK);
     hipLaunchKernelGGL(k_extend_forward, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
-                       c->cfg.hb, dk, df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, db, dc, dn, ds); }
+                       c->cfg.hb, dk, df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, db, dc, dn, ds, dbr, dnc); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_bases, db, ne, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(out_counts, dc, ne * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(out_n, dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(out_stop, ds, n, hipMemcpyDeviceToHost, c->stream));
+  if (out_branch) HIPCHK(hipMemcpyAsync(out_branch, dbr, n, hipMemcpyDeviceToHost, c->stream));
+  if (out_ncount) HIPCHK(hipMemcpyAsync(out_ncount, dnc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  hipFree(dk); hipFree(df); hipFree(db); hipFree(dc); hipFree(dn); hipFree(ds);
+  hipFree(dk); hipFree(df); hipFree(db); hipFree(dc); hipFree(dn); hipFree(ds); hipFree(dbr); hipFree(dnc);
   return finish(c, 0);
 }
 
@@ -1125,7 +1129,7 @@ extern "C" int shk_unitigs_from_seeds(shk_ctx *c, const char *seeds, const uint3
       memcpy(&first[(size_t)i * k], seq[i].data(), k);
       memcpy(&cur[(size_t)i * k], seq[i].data() + seq[i].size() - k, k);
     }
-    int rc = shk_extend_forward(c, cur.data(), first.data(), n, k, abundance_min, 0, max_ext, ext.data(), cnt.data(), en.data(), st.data());
+    int rc = shk_extend_forward(c, cur.data(), first.data(), n, k, abundance_min, 0, max_ext, ext.data(), cnt.data(), en.data(), st.data(), nullptr, nullptr);
     if (rc) return rc;
     for (uint32_t i = 0; i < n; i++) {
       // abundances start as (length - K + 1) copies of the contig's current median (contig_assembly.cpp:3049)
@@ -1148,6 +1152,111 @@ extern "C" int shk_unitigs_from_seeds(shk_ctx *c, const char *seeds, const uint3
     out_len[i] = (uint32_t)seq[i].size();
     out_median[i] = med[i];
   }
+  return SHK_OK;
+}
+
+static std::string walk_rc(const std::string &s) {
+  std::string r(s.rbegin(), s.rend());
+  for (auto &ch : r) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+  return r;
+}
+
+// All unitigs reachable from the seeds: the closure Contiger computes with its work queue
+// (contig_assembly.cpp:3122-3160: every solid neighbour met at a branch becomes a new contig that is
+// extended forward; :3018-3025, :935-954: a unitig found twice is kept once), as rounds of batched
+// extensions. The reference's result is the same SET of sequences (up to reverse complement and to where a
+// pure circle is cut); ids, order and orientation depend on its thread schedule and are not
+// reproduced. FASTA records as the reference writes them (:606-626) minus the L: links of the graph pass.
+extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
+                                uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats) {
+  if (!c || (n && (!seeds || !seed_counts)) || !out_path) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
+  const uint32_t max_ext = max_len - k;
+  struct Unit { std::string seq; int med; };
+  std::vector<Unit> units;
+  std::unordered_set<std::string> ends;     // first k-mer and RC(last k-mer) of every kept unitig (startKmer2unitig)
+  std::unordered_set<std::string> queued;   // start k-mers that were handed to a walk
+  shk_unitig_stats st_;
+  memset(&st_, 0, sizeof(st_));
+  // work items: contig so far, its median, passes left (2 for seeds: forward, RC, forward; 1 for branch neighbours)
+  struct Item { std::string seq; int med; int passes; };
+  std::vector<Item> work;
+  for (uint32_t i = 0; i < n; i++) {
+    std::string s(seeds + (size_t)i * k, k);
+    if (!queued.insert(s).second) continue;
+    work.push_back({s, (int)seed_counts[i], 2});
+  }
+  std::vector<char> cur, first, ext;
+  std::vector<uint32_t> cnt, en, ncount;
+  std::vector<uint8_t> stp, br;
+  while (!work.empty()) {
+    st_.rounds++;
+    std::vector<Item> next;
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<uint32_t> idx;
+      for (uint32_t i = 0; i < work.size(); i++)
+        if (work[i].passes == 2 || pass == 0) idx.push_back(i);
+      if (idx.empty()) continue;
+      const uint32_t m = (uint32_t)idx.size();
+      cur.resize((size_t)m * k); first.resize((size_t)m * k); ext.resize((size_t)m * max_ext);
+      cnt.resize((size_t)m * max_ext); en.resize(m); stp.resize(m); br.resize(m); ncount.resize((size_t)m * 8);
+      for (uint32_t j = 0; j < m; j++) {
+        Item &it = work[idx[j]];
+        if (pass == 1) it.seq = walk_rc(it.seq);
+        memcpy(&first[(size_t)j * k], it.seq.data(), k);
+        memcpy(&cur[(size_t)j * k], it.seq.data() + it.seq.size() - k, k);
+      }
+      int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, 0, max_ext, ext.data(), cnt.data(), en.data(),
+                                  stp.data(), br.data(), ncount.data());
+      if (rc) return rc;
+      st_.extensions += m;
+      for (uint32_t j = 0; j < m; j++) {
+        Item &it = work[idx[j]];
+        std::vector<int> ab(it.seq.size() - k + 1, it.med);
+        uint32_t take = en[j];
+        if (it.seq.size() + take > max_len) { take = max_len - (uint32_t)it.seq.size(); st_.truncated++; }
+        else if (stp[j] == SHK_STOP_BUFFER) st_.truncated++;
+        for (uint32_t t = 0; t < take; t++) ab.push_back((int)cnt[(size_t)j * max_ext + t]);
+        it.seq.append(&ext[(size_t)j * max_ext], take);
+        it.med = walk_median(ab);
+        if (stp[j] == SHK_STOP_BRANCH) {
+          // solid neighbours of the last k-mer start new contigs (contig_assembly.cpp:3133-3160)
+          const std::string last = it.seq.substr(it.seq.size() - k);
+          for (int x = 0; x < 4; x++)
+            if (br[j] & (1u << x)) {
+              std::string s = last.substr(1) + "ACGT"[x];
+              if (!ends.count(s) && queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + x], 1});
+            }
+          for (int z = 0; z < 4; z++)
+            if (br[j] & (16u << z)) {
+              std::string s = walk_rc(std::string(1, "ACGT"[z]) + last.substr(1));
+              if (!ends.count(s) && queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + 4 + z], 1});
+            }
+        }
+      }
+    }
+    // keep every unitig once: its first k-mer and the RC of its last k-mer identify it in either orientation
+    for (auto &it : work) {
+      const std::string f = it.seq.substr(0, k), e = walk_rc(it.seq.substr(it.seq.size() - k));
+      if (ends.count(f) || ends.count(e)) { st_.duplicates++; continue; }
+      ends.insert(f); ends.insert(e);
+      units.push_back({it.seq, it.med});
+    }
+    work.clear();
+    for (auto &it : next)
+      if (!ends.count(it.seq)) work.push_back(it);
+  }
+  FILE *fo = fopen(out_path, "w");
+  if (!fo) return SHK_ERR_IO;
+  for (size_t i = 0; i < units.size(); i++) {
+    const long long len = (long long)units[i].seq.size();
+    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d\n%s\n", i, len, (long long)units[i].med * (len - (long long)k + 1), units[i].med,
+            units[i].seq.c_str());
+    st_.total_len += (uint64_t)len;
+  }
+  fclose(fo);
+  st_.unitigs = units.size();
+  if (stats) *stats = st_;
   return SHK_OK;
 }
 

@@ -25,7 +25,7 @@ __device__ __forceinline__ uint64_t shk_code_seed_rc(unsigned c) { return shk_co
 __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, uint32_t hb, const char *cur_kmers,
                                  const char *first_kmers, uint32_t n, uint32_t k, uint64_t abundance_min, int mark,
                                  uint32_t max_ext, char *out_bases, uint32_t *out_counts, uint32_t *out_n,
-                                 uint8_t *out_stop) {
+                                 uint8_t *out_stop, uint8_t *out_branch, uint32_t *out_ncount) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t kmask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
@@ -43,22 +43,25 @@ __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, u
     fh ^= shk_rol64(shk_code_seed(cc), (k - 1 - j) & 63);
     rh ^= shk_rol64(shk_code_seed_rc(cc), j & 63);
   }
-  if (bad) { out_n[i] = 0; out_stop[i] = SHK_STOP_BAD_SEED; return; }
+  if (bad) { out_n[i] = 0; out_stop[i] = SHK_STOP_BAD_SEED; out_branch[i] = 0; return; }
+  uint32_t ncount[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // filter counts of the neighbours named in `branch`
   const unsigned __int128 wmask = k == 64 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << (2 * k)) - 1);
   uint32_t nout = 0;
-  uint8_t stop = 0, trav;
+  uint8_t stop = 0, trav, branch = 0;   // branch: solid successors (bits 0-3, by base) and solid siblings (bits 4-7) at the stop
   while (!stop) {
     const unsigned s0 = (unsigned)(win >> (2 * (k - 1))) & 3u;
     // successors
     const uint64_t fbase = shk_rol64(fh, 1) ^ shk_rol64(shk_code_seed(s0), k & 63);
     const uint64_t rbase = shk_ror64(rh ^ shk_code_seed_rc(s0), 1);
     uint32_t ncand = 0, xc = 0;
+    uint8_t masks = 0;
+    uint32_t nc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t cnt_x = 0, fh_x = 0, rh_x = 0;
     for (unsigned x = 0; x < 4; x++) {
       const uint64_t f = fbase ^ shk_code_seed(x);
       const uint64_t r = rbase ^ shk_rol64(shk_code_seed_rc(x), (k - 1) & 63);
       const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, mark, &trav);
-      if (cnt >= abundance_min) { ncand++; xc = x; cnt_x = cnt; fh_x = f; rh_x = r; }
+      if (cnt >= abundance_min) { ncand++; xc = x; cnt_x = cnt; fh_x = f; rh_x = r; masks |= (uint8_t)(1u << x); nc[x] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt; }
     }
     // siblings (other predecessors of my successors)
     uint32_t nbefore = 0;
@@ -67,9 +70,13 @@ __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, u
       const uint64_t f = fh ^ shk_rol64(shk_code_seed(s0) ^ shk_code_seed(z), (k - 1) & 63);
       const uint64_t r = rh ^ shk_code_seed_rc(s0) ^ shk_code_seed_rc(z);
       const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, mark, &trav);
-      if (cnt >= abundance_min) nbefore++;
+      if (cnt >= abundance_min) { nbefore++; masks |= (uint8_t)(16u << z); nc[4 + z] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt; }
     }
-    if (nbefore || ncand > 1) { stop = SHK_STOP_BRANCH; break; }
+    if (nbefore || ncand > 1) {
+      stop = SHK_STOP_BRANCH; branch = masks;
+      for (int j = 0; j < 8; j++) ncount[j] = nc[j];
+      break;
+    }
     if (ncand == 0) { stop = SHK_STOP_DEAD_END; break; }
     const unsigned __int128 next = ((win << 2) | xc) & wmask;
     if (next == first) { stop = SHK_STOP_CIRCLE; break; }
@@ -81,4 +88,6 @@ __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, u
   }
   out_n[i] = nout;
   out_stop[i] = stop;
+  out_branch[i] = branch;
+  for (int j = 0; j < 8; j++) out_ncount[(size_t)i * 8 + j] = ncount[j];
 }

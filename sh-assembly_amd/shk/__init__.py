@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_denoise",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
            "shk_last_error_bits"]
@@ -91,7 +91,8 @@ def load(path=None):
     L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
     L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
     L.shk_extend_forward.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32, u64, i32, u32, C.c_char_p, C.POINTER(u32),
-                                     C.POINTER(u32), C.POINTER(C.c_uint8)]
+                                     C.POINTER(u32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(u32)]
+    L.shk_find_unitigs.argtypes = [vp, C.c_char_p, C.POINTER(u32), u32, u32, u64, u32, C.c_char_p, vp]
     L.shk_unitigs_from_seeds.argtypes = [vp, C.c_char_p, C.POINTER(u32), u32, u32, u64, u32, C.c_char_p, C.POINTER(u32),
                                          C.POINTER(C.c_int32), C.POINTER(C.c_uint8)]
     L.shk_denoise.argtypes = [vp, pu64]
@@ -228,6 +229,15 @@ class Context:
         self._chk(self.L.shk_unitigs_from_seeds(self.h, b"".join(seeds), sc, n, k, abundance_min, max_len, out, ln, md, st))
         raw = out.raw
         return [(raw[i * max_len:i * max_len + ln[i]], md[i], (st[2 * i], st[2 * i + 1])) for i in range(n)]
+
+    def find_unitigs(self, seeds, seed_counts, k, abundance_min, max_len, out_path):
+        """writes the FASTA; returns dict(unitigs, total_len, rounds, extensions, duplicates, truncated)"""
+        n = len(seeds)
+        sc = (C.c_uint32 * max(n, 1))(*seed_counts)
+        st = (C.c_uint64 * 6)()
+        self._chk(self.L.shk_find_unitigs(self.h, b"".join(seeds), sc, n, k, abundance_min, max_len, out_path.encode(),
+                                          C.cast(st, C.c_void_p)))
+        return dict(zip(("unitigs", "total_len", "rounds", "extensions", "duplicates", "truncated"), list(st)))
 
     def stage_accept(self, summary):
         self._chk(self.L.shk_stage_accept(self.h, C.byref(summary)))

@@ -80,6 +80,15 @@ class _QF:
         assert rc == 0
         return out.raw[:ln.value], md.value, (st[0], st[1])
 
+    def extend_forward(self, seq: bytes, median, k, abundance_min, max_len):
+        """(sequence, median, stop, branch mask, neighbour counts[8]): one get_unitig_forward (oracle only)"""
+        buf = C.create_string_buffer(seq, max_len + 1)
+        ln, md, br = C.c_uint32(len(seq)), C.c_int(median), C.c_uint8()
+        nc = (C.c_uint32 * 8)()
+        st = self._f("extend_forward")(self.h, buf, C.byref(ln), k, abundance_min, max_len, C.byref(md), C.byref(br), nc)
+        assert st >= 0
+        return buf.raw[:ln.value], md.value, st, br.value, list(nc)
+
     def time_chunks_mt(self, text: bytes, offs, lens, k, nthreads, budget_s):
         """(seconds, k-mers inserted, chunks taken): `nthreads` threads insert under the reference's region locks"""
         n = len(offs)
@@ -147,6 +156,8 @@ class _Lib:
         sig("build_t1", None, [vp, C.POINTER(C.c_char_p), i32, C.c_uint, u64, u32, i32,
                                u64, u32, u64, C.POINTER(u64)])
         if p == "orc_":
+            sig("extend_forward", i32, [vp, C.c_char_p, C.POINTER(u32), C.c_uint, u64, u32, C.POINTER(i32), C.POINTER(C.c_uint8),
+                                        C.POINTER(u32)])
             sig("unitig_from_seed", i32, [vp, C.c_char_p, u32, C.c_uint, u64, u32, C.c_char_p, C.POINTER(u32),
                                           C.POINTER(i32), C.POINTER(C.c_uint8)])
         if p == "ref_":

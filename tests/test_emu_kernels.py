@@ -247,3 +247,112 @@ def _unitig_case(shk_mod, ctx_factory, qb, k, G, nreads, L, err, nseeds):
 def test_unitig_extension_matches_oracle(shk):
     stops = _unitig_case(shk, lambda **kw: _ctx(shk, **kw), qb=12, k=21, G=260, nreads=60, L=60, err=0.004, nseeds=6)
     assert stops   # at least one stop reason seen
+
+
+def _rc(s):
+    return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+
+def _oracle_unitig_set(q, seeds, counts, k, amin, max_len):
+    """independent restatement of the closure (seeds both ways, branch neighbours forward, each unitig once) on the
+    oracle's get_unitig_forward; returns {canonical sequence: median}"""
+    ends, queued, units = set(), set(), {}
+    work = []
+    for s, c in zip(seeds, counts):
+        if s not in queued:
+            queued.add(s)
+            work.append((s, c, 2))
+    while work:
+        nxt, done = [], []
+        for seq, med, passes in work:
+            for p in range(passes):
+                if p == 1:
+                    seq = _rc(seq)
+                seq, med, st, br, nc = q.extend_forward(seq, med, k, amin, max_len)
+                if st == 1:
+                    last = seq[-k:]
+                    for x in range(4):
+                        if br & (1 << x):
+                            nxt.append((last[1:] + b"ACGT"[x:x + 1], nc[x]))
+                    for z in range(4):
+                        if br & (16 << z):
+                            nxt.append((_rc(b"ACGT"[z:z + 1] + last[1:]), nc[4 + z]))
+            done.append((seq, med))
+        for seq, med in done:
+            f, e = seq[:k], _rc(seq[-k:])
+            if f in ends or e in ends:
+                continue
+            ends.update((f, e))
+            units[min(seq, _rc(seq))] = med
+        work = []
+        for s, c in nxt:
+            if s not in ends and s not in queued:
+                queued.add(s)
+                work.append((s, c, 1))
+    return units
+
+
+def _read_unitigs(path, k):
+    out = {}
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    for h, s in zip(lines[0::2], lines[1::2]):
+        if not h:
+            continue
+        fields = dict(x.split(b":", 2)[0::2] for x in h.split()[1:])
+        assert int(fields[b"LN"]) == len(s)
+        med = int(fields[b"km"])
+        assert int(fields[b"KC"]) == med * (len(s) - k + 1)
+        out[min(s, _rc(s))] = med
+    return out
+
+
+def _find_unitigs_case(ctx_factory, tmp_path, qb, k, G, nreads, L, err, seed_every=1, repeat=0):
+    g = synth.make_genome(G, 17)
+    if repeat:      # a segment longer than k occurring twice: real branches in the solid graph
+        import numpy as np
+        g = np.concatenate([g[:3 * G // 5], g[G // 5:G // 5 + repeat], g[3 * G // 5:]])
+    fq = synth.make_fastq(g, nreads, L, err, seed=19)
+    offs, lens = chunks_by_records(fq, max(1, nreads // 3))
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    assert not q.full()
+    ctx = ctx_factory(qb=qb, k=k, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L)
+    ctx.count_chunks(fq, offs, lens)
+    O = cqflibs.oracle()
+    hb = qb + 8
+    seeds, counts = [], []
+    for line in fq.split(b"\n")[1::4][::seed_every]:
+        mid = len(line) // 2 - k // 2
+        km = line[mid:mid + k]
+        if len(km) < k or b"N" in km or km in seeds:
+            continue
+        fh, rh = O.nthash(km, k)
+        c = q.count(min(fh, rh) & ((1 << hb) - 1))
+        if 2 <= c <= 1000000:
+            seeds.append(km)
+            counts.append(c)
+    max_len = 2 * len(g) + k
+    path = str(tmp_path / "unitigs.fa")
+    st = ctx.find_unitigs(seeds, counts, k, 2, max_len, path)
+    got = _read_unitigs(path, k)
+    exp = _oracle_unitig_set(q, seeds, counts, k, 2, max_len)
+    assert got == exp
+    assert st["unitigs"] == len(got) and st["total_len"] == sum(len(s) for s in got) and st["truncated"] == 0
+    ctx.close()
+    q.free()
+    return g, got, st
+
+
+def test_find_unitigs_matches_oracle_closure(shk, tmp_path):
+    g, got, st = _find_unitigs_case(lambda **kw: _ctx(shk, **kw), tmp_path, qb=12, k=21, G=240, nreads=90, L=60, err=0.004, repeat=32, seed_every=45)
+    assert st["rounds"] >= 2 and len(got) >= 3      # branches were followed
+
+
+def test_find_unitigs_rebuilds_an_error_free_genome(shk, tmp_path):
+    """no sequencing errors, a random genome without repeated (k-1)-mers: the solid graph is one path, and the one
+    unitig is the covered part of the genome"""
+    g, got, st = _find_unitigs_case(lambda **kw: _ctx(shk, **kw), tmp_path, qb=12, k=21, G=200, nreads=80, L=60, err=0.0)
+    gs = g.tobytes()
+    for s in got:
+        assert s in gs or _rc(s) in gs
+    assert max(len(s) for s in got) >= 150

@@ -292,3 +292,13 @@ def test_unitig_extension_matches_oracle(qb, k, G, nreads, L, err, nseeds):
     from test_emu_kernels import _unitig_case
     stops = _unitig_case(shk, lambda **kw: _ctx(**kw), qb=qb, k=k, G=G, nreads=nreads, L=L, err=err, nseeds=nseeds)
     assert {1, 2} & stops      # branches (sequencing errors) or dead ends (genome ends) are met
+
+
+@pytest.mark.parametrize("qb,k,G,nreads,L,err,repeat,every", [(17, 47, 20000, 2500, 150, 0.003, 300, 40), (16, 31, 9000, 2000, 100, 0.002, 120, 25)])
+def test_find_unitigs_matches_oracle_closure(tmp_path, qb, k, G, nreads, L, err, repeat, every):
+    """Contiger, set level: all unitigs reachable from sparse seeds (shk_find_unitigs: batched device extensions,
+    branch neighbours queued, each unitig kept once) = an independent closure over the oracle's get_unitig_forward"""
+    from test_emu_kernels import _find_unitigs_case
+    g, got, st = _find_unitigs_case(lambda **kw: _ctx(**kw), tmp_path, qb=qb, k=k, G=G, nreads=nreads, L=L, err=err,
+                                    repeat=repeat, seed_every=every)
+    assert st["rounds"] >= 2 and st["unitigs"] >= 3
