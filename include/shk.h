@@ -19,6 +19,7 @@
  *   shk_extend_forward    get_unitig_forward, the walk that meets no other
  *                         unitig (Contiger, first slice)                   src/contig_assembly.cpp:3028-3218
  *   shk_unitigs_from_seeds its two calls per seed + median abundance        src/contig_assembly.cpp:1886-1904; base/Utility.cpp:27-40
+ *   shk_select_seeds      processDataChunk's seed rule                     src/contig_assembly.cpp:1856-1876
  *   shk_find_unitigs      find_unitigs: seeds + work queue of branch
  *                         neighbours + duplicate removal + writer (set-level) src/contig_assembly.cpp:3122-3160, 935-954, 606-626
  *   shk_stats             runtime->nelts / ndistinct_elts / num_deNoise    cqf/CQF_mt.h:277-288
@@ -210,6 +211,23 @@ typedef struct shk_unitig_stats {
 } shk_unitig_stats;
 int shk_find_unitigs(shk_ctx *ctx, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
                      uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats);
+/* The same in pieces, for callers that feed seeds batch by batch (the Contiger command line): a unitig set that
+ * accumulates over calls. With mark_traveled != 0 every k-mer an extension looks up is marked, so that
+ * shk_select_seeds(use_traveled = 1) on later reads skips seeds inside unitigs that are already known -- the
+ * reference's own pruning (contig_assembly.cpp:1871-1873). */
+typedef struct shk_unitig_set shk_unitig_set;
+shk_unitig_set *shk_unitig_set_new(void);
+void shk_unitig_set_free(shk_unitig_set *u);
+int shk_unitigs_add_seeds(shk_ctx *ctx, shk_unitig_set *u, const char *seeds, const uint32_t *seed_counts, uint32_t n,
+                          uint32_t k, uint64_t abundance_min, uint32_t max_len, int mark_traveled);
+int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *out_path, shk_unitig_stats *stats);
+/* Seeds of the reads in the given FASTQ chunks (processDataChunk, contig_assembly.cpp:1856-1876): the k-mer at
+ * len/2 - k/2 of every read, upper-cased, without 'N', whose filter count lies in [count_min, count_max]; with
+ * use_traveled != 0 the lookup marks the k-mer and a k-mer that was already marked gives no seed. out_seeds
+ * receives *n_out * k bases (capacity cap seeds), out_counts their counts. */
+int shk_select_seeds(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                     const uint64_t *chunk_len, uint32_t nchunks, uint32_t k, uint64_t count_min, uint64_t count_max,
+                     int use_traveled, char *out_seeds, uint32_t *out_counts, uint32_t cap, uint32_t *n_out);
 
 /* per-kernel device time measured with HIP events on the context's stream */
 typedef struct shk_kernel_time {

@@ -302,10 +302,9 @@ static int fetch_err(shk_ctx *c, uint32_t *bits) {
 }
 
 // text + chunk table -> key words in d_words[0]; d_scalars[1] = #words
-static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
-                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
-  // chunk i of this call is labelled chunk_first + i * chunk_mul
-  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+// text -> extents of every read (d_rd_start, d_rd_end, d_rd_chunk); *dtext_out = where the text is on the device
+static int parse_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                       const uint64_t *chunk_len, uint32_t nchunks, const uint8_t **dtext_out, uint64_t *nreads_out) {
   for (uint32_t i = 0; i < nchunks; i++)
     if (chunk_off[i] + chunk_len[i] > text_bytes) return SHK_ERR_ARG;
   const uint8_t *dtext;
@@ -329,6 +328,18 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   { ProfScope ps(c, KP_EMIT_READS);
     hipLaunchKernelGGL(k_emit_reads, dim3(nchunks * SHK_PARSE_SEGS), dim3(c->threads), 0, c->stream, dtext, c->d_chunk_off, c->d_chunk_len,
                        c->d_reads_base, c->d_nlines, c->d_rd_start, c->d_rd_end, c->d_rd_chunk); }
+  *dtext_out = dtext;
+  *nreads_out = nreads;
+  return SHK_OK;
+}
+
+static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
+  // chunk i of this call is labelled chunk_first + i * chunk_mul
+  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+  const uint8_t *dtext;
+  uint64_t nreads;
+  { int rc = parse_stage(c, text, on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads); if (rc) return rc; }
   uint32_t groups = c->hash_groups;
   { uint64_t need = nreads / (c->threads / SHK_WAVE) + 1; if (need < groups) groups = (uint32_t)need; }
   { ProfScope ps(c, KP_COUNT_KEYS);
@@ -1068,6 +1079,42 @@ extern "C" int shk_lookup(shk_ctx *c, const uint64_t *keys, uint64_t n, int on_d
   return finish(c, 0);
 }
 
+// ------------------------------------------------------------------ Contiger: seeds (processDataChunk, contig_assembly.cpp:1839-1884)
+extern "C" int shk_select_seeds(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                                const uint64_t *chunk_len, uint32_t nchunks, uint32_t k, uint64_t count_min, uint64_t count_max,
+                                int use_traveled, char *out_seeds, uint32_t *out_counts, uint32_t cap, uint32_t *n_out) {
+  if (!c || !text || !out_seeds || !out_counts || !n_out || nchunks == 0 || nchunks > SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  const uint8_t *dtext;
+  uint64_t nreads;
+  int rc = parse_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads);
+  if (rc) return finish(c, rc);
+  *n_out = 0;
+  if (nreads == 0) return finish(c, 0);
+  char *ds = nullptr; uint32_t *dc = nullptr;
+  if (dmalloc(&ds, nreads * k) || dmalloc(&dc, nreads)) return SHK_ERR_HIP;
+  { ProfScope ps(c, KP_WALK);
+    hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
+                       c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, nreads, k, count_min, count_max, use_traveled ? 1 : 2, ds, dc); }
+  HIPCHK(hipGetLastError());
+  std::vector<char> hs(nreads * k);
+  std::vector<uint32_t> hc(nreads);
+  HIPCHK(hipMemcpyAsync(hs.data(), ds, nreads * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hc.data(), dc, nreads * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipFree(ds); hipFree(dc);
+  uint32_t n = 0;
+  for (uint64_t r = 0; r < nreads; r++)
+    if (hc[r]) {                       // 0 = no seed from this read
+      if (n >= cap) return finish(c, SHK_ERR_BATCH);
+      memcpy(out_seeds + (size_t)n * k, &hs[r * k], k);
+      out_counts[n++] = hc[r];
+    }
+  *n_out = n;
+  return finish(c, 0);
+}
+
 // ------------------------------------------------------------------ Contiger: unitig extension (first slice)
 extern "C" int shk_extend_forward(shk_ctx *c, const char *cur_kmers, const char *first_kmers, uint32_t n, uint32_t k,
                                   uint64_t abundance_min, int mark_traveled, uint32_t max_ext, char *out_bases,
@@ -1167,23 +1214,29 @@ static std::string walk_rc(const std::string &s) {
 // extensions. The reference's result is the same SET of sequences (up to reverse complement and to where a
 // pure circle is cut); ids, order and orientation depend on its thread schedule and are not
 // reproduced. FASTA records as the reference writes them (:606-626) minus the L: links of the graph pass.
-extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
-                                uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats) {
-  if (!c || (n && (!seeds || !seed_counts)) || !out_path) return SHK_ERR_ARG;
-  if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
-  const uint32_t max_ext = max_len - k;
+struct shk_unitig_set {
   struct Unit { std::string seq; int med; };
   std::vector<Unit> units;
   std::unordered_set<std::string> ends;     // first k-mer and RC(last k-mer) of every kept unitig (startKmer2unitig)
   std::unordered_set<std::string> queued;   // start k-mers that were handed to a walk
-  shk_unitig_stats st_;
-  memset(&st_, 0, sizeof(st_));
-  // work items: contig so far, its median, passes left (2 for seeds: forward, RC, forward; 1 for branch neighbours)
+  shk_unitig_stats st;
+  shk_unitig_set() { memset(&st, 0, sizeof(st)); }
+};
+extern "C" shk_unitig_set *shk_unitig_set_new(void) { return new shk_unitig_set(); }
+extern "C" void shk_unitig_set_free(shk_unitig_set *u) { delete u; }
+
+extern "C" int shk_unitigs_add_seeds(shk_ctx *c, shk_unitig_set *u, const char *seeds, const uint32_t *seed_counts, uint32_t n,
+                                     uint32_t k, uint64_t abundance_min, uint32_t max_len, int mark_traveled) {
+  if (!c || !u || (n && (!seeds || !seed_counts))) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
+  const uint32_t max_ext = max_len - k;
+  shk_unitig_stats &st_ = u->st;
+  // work items: contig so far, its median, passes (2 for seeds: forward, RC, forward; 1 for branch neighbours)
   struct Item { std::string seq; int med; int passes; };
   std::vector<Item> work;
   for (uint32_t i = 0; i < n; i++) {
     std::string s(seeds + (size_t)i * k, k);
-    if (!queued.insert(s).second) continue;
+    if (u->ends.count(s) || !u->queued.insert(s).second) continue;
     work.push_back({s, (int)seed_counts[i], 2});
   }
   std::vector<char> cur, first, ext;
@@ -1206,8 +1259,8 @@ extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *s
         memcpy(&first[(size_t)j * k], it.seq.data(), k);
         memcpy(&cur[(size_t)j * k], it.seq.data() + it.seq.size() - k, k);
       }
-      int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, 0, max_ext, ext.data(), cnt.data(), en.data(),
-                                  stp.data(), br.data(), ncount.data());
+      int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, mark_traveled, max_ext, ext.data(), cnt.data(),
+                                  en.data(), stp.data(), br.data(), ncount.data());
       if (rc) return rc;
       st_.extensions += m;
       for (uint32_t j = 0; j < m; j++) {
@@ -1225,12 +1278,12 @@ extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *s
           for (int x = 0; x < 4; x++)
             if (br[j] & (1u << x)) {
               std::string s = last.substr(1) + "ACGT"[x];
-              if (!ends.count(s) && queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + x], 1});
+              if (!u->ends.count(s) && u->queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + x], 1});
             }
           for (int z = 0; z < 4; z++)
             if (br[j] & (16u << z)) {
               std::string s = walk_rc(std::string(1, "ACGT"[z]) + last.substr(1));
-              if (!ends.count(s) && queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + 4 + z], 1});
+              if (!u->ends.count(s) && u->queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + 4 + z], 1});
             }
         }
       }
@@ -1238,26 +1291,41 @@ extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *s
     // keep every unitig once: its first k-mer and the RC of its last k-mer identify it in either orientation
     for (auto &it : work) {
       const std::string f = it.seq.substr(0, k), e = walk_rc(it.seq.substr(it.seq.size() - k));
-      if (ends.count(f) || ends.count(e)) { st_.duplicates++; continue; }
-      ends.insert(f); ends.insert(e);
-      units.push_back({it.seq, it.med});
+      if (u->ends.count(f) || u->ends.count(e)) { st_.duplicates++; continue; }
+      u->ends.insert(f); u->ends.insert(e);
+      u->units.push_back({it.seq, it.med});
     }
     work.clear();
     for (auto &it : next)
-      if (!ends.count(it.seq)) work.push_back(it);
+      if (!u->ends.count(it.seq)) work.push_back(it);
   }
+  return SHK_OK;
+}
+
+extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *out_path, shk_unitig_stats *stats) {
+  if (!u || !out_path) return SHK_ERR_ARG;
   FILE *fo = fopen(out_path, "w");
   if (!fo) return SHK_ERR_IO;
-  for (size_t i = 0; i < units.size(); i++) {
-    const long long len = (long long)units[i].seq.size();
-    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d\n%s\n", i, len, (long long)units[i].med * (len - (long long)k + 1), units[i].med,
-            units[i].seq.c_str());
-    st_.total_len += (uint64_t)len;
+  u->st.total_len = 0;
+  for (size_t i = 0; i < u->units.size(); i++) {
+    const long long len = (long long)u->units[i].seq.size();
+    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d\n%s\n", i, len, (long long)u->units[i].med * (len - (long long)k + 1), u->units[i].med,
+            u->units[i].seq.c_str());
+    u->st.total_len += (uint64_t)len;
   }
   fclose(fo);
-  st_.unitigs = units.size();
-  if (stats) *stats = st_;
+  u->st.unitigs = u->units.size();
+  if (stats) *stats = u->st;
   return SHK_OK;
+}
+
+extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
+                                uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats) {
+  if (!out_path) return SHK_ERR_ARG;
+  shk_unitig_set u;
+  int rc = shk_unitigs_add_seeds(c, &u, seeds, seed_counts, n, k, abundance_min, max_len, 0);
+  if (!rc) rc = shk_unitig_set_write(&u, k, out_path, stats);
+  return rc;
 }
 
 extern "C" int shk_profile_enable(shk_ctx *c, int on) { if (!c) return SHK_ERR_ARG; c->prof_on = on; return SHK_OK; }

@@ -91,3 +91,35 @@ __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, u
   out_branch[i] = branch;
   for (int j = 0; j < 8; j++) out_ncount[(size_t)i * 8 + j] = ncount[j];
 }
+
+// Seed of a read (processDataChunk, contig_assembly.cpp:1856-1876): the k-mer at len/2 - k/2, upper-cased, no 'N';
+// looked up (and marked traveled when mark == 1, as count_key_value_set_traveled does); kept when it was not
+// traveled before and its count lies in [count_min, count_max]. One thread per read; out_counts[r] = 0 means none.
+__global__ void k_select_seeds(uint8_t *tab, uint64_t q_lo, uint64_t nslots, uint32_t hb, const uint8_t *text,
+                               const uint64_t *rd_start, const uint64_t *rd_end, uint64_t nreads, uint32_t k, uint64_t count_min,
+                               uint64_t count_max, int mark, char *out_seeds, uint32_t *out_counts) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nreads) return;
+  out_counts[r] = 0;
+  const uint64_t st = rd_start[r], en = rd_end[r];
+  if (en < st || en - st < k || en - st > SHK_MAX_READ) return;
+  const uint32_t len = (uint32_t)(en - st);
+  const int middle = (int)(len / 2) - (int)(k / 2);
+  if (middle < 0 || (uint32_t)middle > len - k) return;
+  uint64_t fh = 0, rh = 0;
+  for (uint32_t j = 0; j < k; j++) {
+    unsigned ch = text[st + (uint32_t)middle + j];
+    if (ch >= 'a' && ch <= 'z') ch -= 32;        // to_upper_DNA
+    const unsigned cc = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+    if (cc > 3) return;                          // 'N' (any byte that is not a base has no seed here)
+    out_seeds[r * k + j] = (char)ch;
+    fh ^= shk_rol64(shk_code_seed(cc), (k - 1 - j) & 63);
+    rh ^= shk_rol64(shk_code_seed_rc(cc), j & 63);
+  }
+  const uint64_t kmask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
+  uint8_t trav = 0;
+  const uint64_t cnt = shk_lookup_one(tab, (fh < rh ? fh : rh) & kmask, q_lo, nslots, mark, &trav);
+  if (mark == 1 && trav) return;
+  if (cnt < count_min || cnt > count_max) return;
+  out_counts[r] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;
+}

@@ -302,3 +302,51 @@ def test_find_unitigs_matches_oracle_closure(tmp_path, qb, k, G, nreads, L, err,
     g, got, st = _find_unitigs_case(lambda **kw: _ctx(**kw), tmp_path, qb=qb, k=k, G=G, nreads=nreads, L=L, err=err,
                                     repeat=repeat, seed_every=every)
     assert st["rounds"] >= 2 and st["unitigs"] >= 3
+
+
+def test_contiger_cli_unitig_set(tmp_path):
+    """sh-assembly_amd/bin/Contiger (reference flags) on a .cqf + two FASTQ files: the sequences in unitigs.fa are the
+    closure the oracle computes from ALL seeds (the command line prunes seeds with the traveled bits batch by batch, as
+    the reference does; which seed finds a unitig changes its median, not the set of sequences)"""
+    import subprocess
+    from test_emu_kernels import _oracle_unitig_set, _read_unitigs
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "sh-assembly_amd", "bin", "Contiger")
+    assert os.path.exists(exe), "build with make -C sh-assembly_amd"
+    qb, k, G = 17, 47, 20000
+    g = synth.make_genome(G, 23)
+    g = np.concatenate([g[:12000], g[3000:3400], g[12000:]])          # a 400-base repeat: real branches
+    fq1 = synth.make_fastq(g, 1400, 150, 0.003, seed=29)
+    fq2 = synth.make_fastq(g, 1400, 150, 0.003, seed=31, name_prefix="s")
+    (tmp_path / "a.fq").write_bytes(fq1)
+    (tmp_path / "b.fq").write_bytes(fq2)
+    (tmp_path / "files.txt").write_text("a.fq\nb.fq\n")
+    fq = fq1 + fq2
+    offs, lens = chunks_by_records(fq, 700)
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    assert not q.full()
+    cqf = str(tmp_path / "k47.cqf")
+    q.serialize(cqf)
+    out = str(tmp_path / "unitigs.fa")
+    r = subprocess.run([exe, "-k", str(k), "-i", str(tmp_path / "files.txt"), "-c", cqf, "-o", out, "--part-size", "60000",
+                        "--overhead", "4000", "--batch-chunks", "3", "--max-len", str(2 * len(g) + k)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = _read_unitigs(out, k)
+    O = cqflibs.oracle()
+    seeds, counts = [], []
+    for line in fq.split(b"\n")[1::4]:
+        mid = len(line) // 2 - k // 2
+        km = line[mid:mid + k]
+        if len(km) < k or b"N" in km or km in seeds:
+            continue
+        fh, rh = O.nthash(km, k)
+        c = q.count(min(fh, rh) & ((1 << (qb + 8)) - 1))
+        if 2 <= c <= 1000000:
+            seeds.append(km)
+            counts.append(c)
+    exp = _oracle_unitig_set(q, seeds, counts, k, 2, 2 * len(g) + k)
+    assert set(got) == set(exp), r.stderr[-300:]
+    assert "truncated: 0" in r.stderr and len(got) >= 3
+    q.free()
