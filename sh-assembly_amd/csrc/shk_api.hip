@@ -1229,15 +1229,19 @@ extern "C" int shk_unitigs_add_seeds(shk_ctx *c, shk_unitig_set *u, const char *
                                      uint32_t k, uint64_t abundance_min, uint32_t max_len, int mark_traveled) {
   if (!c || !u || (n && (!seeds || !seed_counts))) return SHK_ERR_ARG;
   if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
-  const uint32_t max_ext = max_len - k;
+  // A launch extends every open end by at most `step` bases (bounded result buffers); ends that fill their
+  // buffer simply continue in the next launch. At most `mmax` ends per launch.
+  uint32_t step = max_len - k < 2048 ? max_len - k : 2048;
+  if (const char *e = getenv("SHK_WALK_STEP")) { int v = atoi(e); if (v > 0 && (uint32_t)v < step) step = (uint32_t)v; }   // tests: force continuations
+  const uint32_t mmax = (uint32_t)((1ull << 30) / ((uint64_t)step * 5)) + 1;
   shk_unitig_stats &st_ = u->st;
   // work items: contig so far, its median, passes (2 for seeds: forward, RC, forward; 1 for branch neighbours)
-  struct Item { std::string seq; int med; int passes; };
+  struct Item { std::string seq; int med; int passes; std::vector<int> ab; bool open; };
   std::vector<Item> work;
   for (uint32_t i = 0; i < n; i++) {
     std::string s(seeds + (size_t)i * k, k);
     if (u->ends.count(s) || !u->queued.insert(s).second) continue;
-    work.push_back({s, (int)seed_counts[i], 2});
+    work.push_back({s, (int)seed_counts[i], 2, {}, false});
   }
   std::vector<char> cur, first, ext;
   std::vector<uint32_t> cnt, en, ncount;
@@ -1246,46 +1250,58 @@ extern "C" int shk_unitigs_add_seeds(shk_ctx *c, shk_unitig_set *u, const char *
     st_.rounds++;
     std::vector<Item> next;
     for (int pass = 0; pass < 2; pass++) {
-      std::vector<uint32_t> idx;
+      std::vector<uint32_t> open;
       for (uint32_t i = 0; i < work.size(); i++)
-        if (work[i].passes == 2 || pass == 0) idx.push_back(i);
-      if (idx.empty()) continue;
-      const uint32_t m = (uint32_t)idx.size();
-      cur.resize((size_t)m * k); first.resize((size_t)m * k); ext.resize((size_t)m * max_ext);
-      cnt.resize((size_t)m * max_ext); en.resize(m); stp.resize(m); br.resize(m); ncount.resize((size_t)m * 8);
-      for (uint32_t j = 0; j < m; j++) {
-        Item &it = work[idx[j]];
-        if (pass == 1) it.seq = walk_rc(it.seq);
-        memcpy(&first[(size_t)j * k], it.seq.data(), k);
-        memcpy(&cur[(size_t)j * k], it.seq.data() + it.seq.size() - k, k);
-      }
-      int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, mark_traveled, max_ext, ext.data(), cnt.data(),
-                                  en.data(), stp.data(), br.data(), ncount.data());
-      if (rc) return rc;
-      st_.extensions += m;
-      for (uint32_t j = 0; j < m; j++) {
-        Item &it = work[idx[j]];
-        std::vector<int> ab(it.seq.size() - k + 1, it.med);
-        uint32_t take = en[j];
-        if (it.seq.size() + take > max_len) { take = max_len - (uint32_t)it.seq.size(); st_.truncated++; }
-        else if (stp[j] == SHK_STOP_BUFFER) st_.truncated++;
-        for (uint32_t t = 0; t < take; t++) ab.push_back((int)cnt[(size_t)j * max_ext + t]);
-        it.seq.append(&ext[(size_t)j * max_ext], take);
-        it.med = walk_median(ab);
-        if (stp[j] == SHK_STOP_BRANCH) {
-          // solid neighbours of the last k-mer start new contigs (contig_assembly.cpp:3133-3160)
-          const std::string last = it.seq.substr(it.seq.size() - k);
-          for (int x = 0; x < 4; x++)
-            if (br[j] & (1u << x)) {
-              std::string s = last.substr(1) + "ACGT"[x];
-              if (!u->ends.count(s) && u->queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + x], 1});
-            }
-          for (int z = 0; z < 4; z++)
-            if (br[j] & (16u << z)) {
-              std::string s = walk_rc(std::string(1, "ACGT"[z]) + last.substr(1));
-              if (!u->ends.count(s) && u->queued.insert(s).second) next.push_back({s, (int)ncount[(size_t)j * 8 + 4 + z], 1});
-            }
+        if (work[i].passes == 2 || pass == 0) {
+          Item &it = work[i];
+          if (pass == 1) it.seq = walk_rc(it.seq);
+          // abundances start as (length - K + 1) copies of the contig's current median (contig_assembly.cpp:3049)
+          it.ab.assign(it.seq.size() - k + 1, it.med);
+          it.open = true;
+          open.push_back(i);
         }
+      while (!open.empty()) {
+        const uint32_t m = open.size() < mmax ? (uint32_t)open.size() : mmax;
+        cur.resize((size_t)m * k); first.resize((size_t)m * k); ext.resize((size_t)m * step);
+        cnt.resize((size_t)m * step); en.resize(m); stp.resize(m); br.resize(m); ncount.resize((size_t)m * 8);
+        for (uint32_t j = 0; j < m; j++) {
+          Item &it = work[open[j]];
+          memcpy(&first[(size_t)j * k], it.seq.data(), k);
+          memcpy(&cur[(size_t)j * k], it.seq.data() + it.seq.size() - k, k);
+        }
+        int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, mark_traveled, step, ext.data(), cnt.data(),
+                                    en.data(), stp.data(), br.data(), ncount.data());
+        if (rc) return rc;
+        st_.extensions += m;
+        std::vector<uint32_t> still(open.begin() + m, open.end());
+        for (uint32_t j = 0; j < m; j++) {
+          Item &it = work[open[j]];
+          uint32_t take = en[j];
+          bool cut = false;
+          if (it.seq.size() + take >= max_len) { take = max_len - (uint32_t)it.seq.size(); cut = stp[j] == SHK_STOP_BUFFER || take < en[j]; }
+          for (uint32_t t = 0; t < take; t++) it.ab.push_back((int)cnt[(size_t)j * step + t]);
+          it.seq.append(&ext[(size_t)j * step], take);
+          if (stp[j] == SHK_STOP_BUFFER && !cut) { still.push_back(open[j]); continue; }   // goes on in the next launch
+          if (cut) st_.truncated++;
+          it.open = false;
+          it.med = walk_median(it.ab);
+          it.ab.clear(); it.ab.shrink_to_fit();
+          if (stp[j] == SHK_STOP_BRANCH && !cut) {
+            // solid neighbours of the last k-mer start new contigs (contig_assembly.cpp:3133-3160)
+            const std::string last = it.seq.substr(it.seq.size() - k);
+            for (int x = 0; x < 4; x++)
+              if (br[j] & (1u << x)) {
+                std::string s2 = last.substr(1) + "ACGT"[x];
+                if (!u->ends.count(s2) && u->queued.insert(s2).second) next.push_back({s2, (int)ncount[(size_t)j * 8 + x], 1, {}, false});
+              }
+            for (int z = 0; z < 4; z++)
+              if (br[j] & (16u << z)) {
+                std::string s2 = walk_rc(std::string(1, "ACGT"[z]) + last.substr(1));
+                if (!u->ends.count(s2) && u->queued.insert(s2).second) next.push_back({s2, (int)ncount[(size_t)j * 8 + 4 + z], 1, {}, false});
+              }
+          }
+        }
+        open.swap(still);
       }
     }
     // keep every unitig once: its first k-mer and the RC of its last k-mer identify it in either orientation

@@ -348,7 +348,8 @@ def _find_unitigs_case(ctx_factory, tmp_path, qb, k, G, nreads, L, err, seed_eve
     return g, got, st
 
 
-def test_find_unitigs_matches_oracle_closure(shk, tmp_path):
+def test_find_unitigs_matches_oracle_closure(shk, tmp_path, monkeypatch):
+    monkeypatch.setenv("SHK_WALK_STEP", "17")       # walks continue over several launches
     g, got, st = _find_unitigs_case(lambda **kw: _ctx(shk, **kw), tmp_path, qb=12, k=21, G=240, nreads=90, L=60, err=0.004, repeat=32, seed_every=45)
     assert st["rounds"] >= 2 and len(got) >= 3      # branches were followed
 
