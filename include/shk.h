@@ -199,8 +199,9 @@ int shk_unitigs_from_seeds(shk_ctx *ctx, const char *seeds, const uint32_t *seed
                            uint64_t abundance_min, uint32_t max_len, char *out_seq, uint32_t *out_len,
                            int32_t *out_median, uint8_t *out_stop);
 
-/* All unitigs reachable from the seeds, written as FASTA (`>i LN:i:len KC:i:median*(len-k+1) km:f:median`, the
- * reference's record without the L: links of its graph pass): seeds are extended in both directions, every solid
+/* All unitigs reachable from the seeds, written as FASTA in the reference's record grammar
+ * (`>i LN:i:len KC:i:median*(len-k+1) km:f:median L:+:j:+ ... L:-:j:- ...`, successors in A,C,G,T order, predecessors
+ * in T,G,C,A order, src/contig_assembly.cpp:606-626, 1012-1084): seeds are extended in both directions, every solid
  * neighbour met at a branch starts a new contig (the reference's work queue), a unitig found more than once is
  * kept once. The reference produces the same set of sequences up to reverse complement; ids and order are its
  * thread schedule's and are not reproduced. */

@@ -13,6 +13,7 @@
 #include <string>
 #include <algorithm>
 #include <unordered_set>
+#include <unordered_map>
 
 #include "kmer_kernels.hip"
 #include "partition_kernels.hip"
@@ -1322,11 +1323,35 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
   if (!u || !out_path) return SHK_ERR_ARG;
   FILE *fo = fopen(out_path, "w");
   if (!fo) return SHK_ERR_IO;
+  // final numbering and the start-k-mer map of the graph pass (track_kmer_worker, contig_assembly.cpp:956-1010):
+  // first k-mer -> +id, RC(last k-mer) -> -id (ids from 1; a unitig whose two keys coincide keeps +id)
+  std::unordered_map<std::string, long long> start;
+  start.reserve(u->units.size() * 2);
+  for (size_t i = 0; i < u->units.size(); i++) {
+    const std::string &sq = u->units[i].seq;
+    const std::string f = sq.substr(0, k), e = walk_rc(sq.substr(sq.size() - k));
+    if (f != e) start[e] = -(long long)(i + 1);
+    start[f] = (long long)(i + 1);
+  }
   u->st.total_len = 0;
   for (size_t i = 0; i < u->units.size(); i++) {
-    const long long len = (long long)u->units[i].seq.size();
-    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d\n%s\n", i, len, (long long)u->units[i].med * (len - (long long)k + 1), u->units[i].med,
-            u->units[i].seq.c_str());
+    const std::string &sq = u->units[i].seq;
+    const long long len = (long long)sq.size();
+    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d", i, len, (long long)u->units[i].med * (len - (long long)k + 1), u->units[i].med);
+    // build_graph_worker (:1012-1084) + writer (:611-624): successors in A,C,G,T order, predecessors in T,G,C,A order
+    std::string fix = sq.substr(sq.size() - k + 1);
+    for (int x = 0; x < 4; x++) {
+      auto it = start.find(fix + "ACGT"[x]);
+      if (it == start.end()) continue;
+      if (it->second > 0) fprintf(fo, " L:+:%lld:+", it->second - 1); else fprintf(fo, " L:+:%lld:-", -it->second - 1);
+    }
+    fix = walk_rc(sq.substr(0, k - 1));
+    for (int x = 3; x >= 0; x--) {
+      auto it = start.find(fix + "ACGT"[x]);
+      if (it == start.end()) continue;
+      if (it->second > 0) fprintf(fo, " L:-:%lld:+", it->second - 1); else fprintf(fo, " L:-:%lld:-", -it->second - 1);
+    }
+    fprintf(fo, "\n%s\n", sq.c_str());
     u->st.total_len += (uint64_t)len;
   }
   fclose(fo);

@@ -3,8 +3,8 @@
 // reference's chunker, takes every read's seed k-mer (shk_select_seeds), extends the seeds on the device and
 // follows branches (shk_unitigs_add_seeds), and writes unitigs.fa. Seeds are taken one chunk at a time by default: the
 // traveled bits set while a chunk's unitigs are walked prune the next chunk's seeds (16 chunks per batch: 6.0 s on the
-// 4 Mb demo, 1 chunk: 0.9 s). Not yet here: the L: links of the graph pass
-// (contig_assembly.cpp:1012-1084) and the reference's ids/order (they depend on its thread schedule).
+// 4 Mb demo, 1 chunk: 0.9 s). Records carry the L: links of the graph pass
+// (contig_assembly.cpp:1012-1084); ids and order are this program's, the reference's depend on its thread schedule.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -294,17 +294,38 @@ def _oracle_unitig_set(q, seeds, counts, k, amin, max_len):
 
 
 def _read_unitigs(path, k):
-    out = {}
+    """{canonical sequence: median}; checks the record grammar (LN, KC, km) and every L: link against the sequences:
+    `L:+:j:+` <=> unitig j starts with my last k-1 bases + x, `L:+:j:-` <=> RC(j) does; `L:-:...` the same for RC(me)
+    (build_graph_worker, contig_assembly.cpp:1012-1084), and no such neighbour is left unlinked"""
+    out, recs = {}, []
     with open(path, "rb") as f:
         lines = f.read().split(b"\n")
     for h, s in zip(lines[0::2], lines[1::2]):
         if not h:
             continue
-        fields = dict(x.split(b":", 2)[0::2] for x in h.split()[1:])
+        parts = h.split()
+        assert parts[0] == b">%d" % len(recs)
+        fields = dict(x.split(b":", 2)[0::2] for x in parts[1:4])
         assert int(fields[b"LN"]) == len(s)
         med = int(fields[b"km"])
         assert int(fields[b"KC"]) == med * (len(s) - k + 1)
+        links = [tuple(x.split(b":")[1:]) for x in parts[4:]]
+        recs.append((s, links))
         out[min(s, _rc(s))] = med
+    starts = {}
+    for j, (s, _) in enumerate(recs):
+        f, e = s[:k], _rc(s[-k:])
+        if f != e:
+            starts[e] = (j, b"-")
+        starts[f] = (j, b"+")
+    for s, links in recs:
+        want = []
+        for side, fix, order in ((b"+", s[-(k - 1):], b"ACGT"), (b"-", _rc(s[:k - 1]), b"TGCA")):
+            for x in order:
+                hit = starts.get(fix + bytes([x]))
+                if hit:
+                    want.append((side, b"%d" % hit[0], hit[1]))
+        assert links == want
     return out
 
 
