@@ -188,13 +188,6 @@ def cpu_baseline(torch, text_cpu, offs, lens, k, qb, budget_s=12.0):
     return out
 
 
-class _CAI:
-    """expose a raw device pointer to torch through __cuda_array_interface__"""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
