@@ -352,3 +352,49 @@ def test_contiger_cli_unitig_set(tmp_path):
     assert set(got) == set(exp), r.stderr[-300:]
     assert "truncated: 0" in r.stderr and len(got) >= 3
     q.free()
+
+
+def test_full_size_schedule_independent_of_batching(tmp_path):
+    """BASELINE size (C. elegans sizing: qb 29, one bench batch of 8 M reads = 832 M k-mers) with deNoise points inside
+    the batch: table, counters, rounds and removed counts do not depend on how the 302 chunks are split into calls (the
+    schedule is a property of the chunk sequence, CQF_mt.h:837); the exported .cqf decodes consistently on the CPU."""
+    import hashlib
+    import importlib.util
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dev = torch.device("cuda", 0)
+    qb, K, L, R = 29, 47, 150, 8_000_000
+    genome = torch.randint(0, 4, (100_000_000,), device=dev, dtype=torch.uint8,
+                           generator=torch.Generator(device=dev).manual_seed(9))
+    text = bench.gen_batch_torch(torch, genome, R, L, 0.00234, 0, 91, dev)
+    torch.cuda.synchronize()
+    rec = 2 * L + bench.NAME_W + 6
+    offs, lens = bench.chunk_table(R, rec)
+    results = []
+    for calls in (1, 3):
+        ctx = _ctx(qb=qb, k=K, trigger=60_000_000, num_denoise=2, max_batch_bytes=64, max_batch_keys=R * (L - K + 1) + 4096,
+                   max_batch_reads=R + 1024)
+        per = (len(offs) + calls - 1) // calls
+        rounds = removed = kmers = 0
+        for i in range(0, len(offs), per):
+            st = ctx.count_chunks(text.data_ptr(), offs[i:i + per], lens[i:i + per], on_device=True, text_bytes=text.numel())
+            rounds += st["denoise_rounds"]
+            removed += st["removed"]
+            kmers += st["kmers"]
+        t = ctx.totals()
+        assert t.nelts == kmers - removed and rounds == 2 and removed > 0
+        results.append((hashlib.sha256(ctx.blocks()).hexdigest(), t.nelts, t.ndistinct, rounds, removed))
+        if calls == 1:
+            p = str(tmp_path / "full.cqf")
+            ctx.export_cqf(p)
+            o = cqflibs.oracle().load(p)
+            assert o.check_offset()
+            assert o.L.orc_qf_dump(o.h, None, None, 0) == t.ndistinct      # entries found by the CPU decode
+            assert (o.nelts(), o.ndistinct()) == (t.nelts, t.ndistinct)    # header counters
+            o.free()
+            os.remove(p)
+        ctx.close()
+    assert results[0] == results[1]
