@@ -37,7 +37,7 @@ static void usage(const char *argv0) {
 
 int main(int argc, char *argv[]) {
   int K = -1, device = 0;
-  long long amin = 2, xmin = 2, xmax = 1000000, max_len = 1 << 16, part_size = 1LL << 23, overhead = 65535, batch_chunks = 1;
+  long long amin = 2, xmin = 2, xmax = 1000000, max_len = 1 << 26, part_size = 1LL << 23, overhead = 65535, batch_chunks = 1;
   string flist, cqf, output = "unitigs.fa";
   char fmt = 'f';
   if (argc == 1) { usage(argv[0]); return 0; }
