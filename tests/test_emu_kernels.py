@@ -383,3 +383,4 @@ def test_find_unitigs_rebuilds_an_error_free_genome(shk, tmp_path):
     for s in got:
         assert s in gs or _rc(s) in gs
     assert max(len(s) for s in got) >= 150
+

@@ -398,3 +398,35 @@ def test_full_size_schedule_independent_of_batching(tmp_path):
             os.remove(p)
         ctx.close()
     assert results[0] == results[1]
+
+
+def test_region_hash_overflow_halves_the_chunk_range():
+    """more than 512 distinct new keys for one 256-quotient region in one pass: the pass reports it before anything
+    is written, the host takes fewer chunks at once; a single chunk that overflows is a hard error that leaves the
+    table untouched"""
+    import torch
+    import shk
+    from cqf_canon import build_blocks
+    qb, hb = 11, 19
+    keys = [((300 + (i % 200)) << 8) | (i * 7 % 256) for i in range(700)]      # 700 distinct keys, quotients 300..499 (region 1)
+    keys = list(dict.fromkeys(keys))
+    assert len(keys) > 600
+    ctx = _ctx(qb=qb, k=21, max_batch_bytes=64, max_batch_keys=1 << 12)
+    # two chunks of about half the keys each: every half fits, both together do not
+    half = len(keys) // 2
+    words = [k | (0 << hb) for k in keys[:half]] + [k | (1 << hb) for k in keys[half:]]
+    t = _upload(words)
+    torch.cuda.synchronize()
+    st = ctx.count_words(t.data_ptr(), t.numel(), 2)
+    assert st["kmers"] == len(keys)
+    want = build_blocks(qb, hb, {k: 1 for k in keys})
+    assert ctx.blocks() == want
+    # one chunk with another 600 new keys for the same region cannot be split
+    more = [((300 + (i % 200)) << 8) | ((i * 7 + 3) % 256) for i in range(1500)]
+    more = [k for k in dict.fromkeys(more) if k not in set(keys)][:600]
+    t2 = _upload(more)
+    torch.cuda.synchronize()
+    with pytest.raises(shk.ShkError):
+        ctx.count_words(t2.data_ptr(), t2.numel(), 1)
+    assert ctx.blocks() == want
+    ctx.close()
