@@ -259,7 +259,15 @@ __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, cons
 __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
                              const uint64_t *nreads_p, const uint16_t *rd_chunk,
                              uint32_t chunk_first, uint32_t chunk_mul, const uint64_t *key_base, uint32_t k, uint32_t hb,
-                             uint64_t *words, uint64_t cap, uint32_t *err) {
+                             uint64_t *words, uint64_t cap, uint32_t *err, uint64_t *hist0, uint32_t dig_shift, uint32_t dig_bits,
+                             uint64_t q_lo) {
+  // hist0 != null: also count the keys per first partition digit (digit = (region >> dig_shift) & (2^dig_bits - 1)),
+  // which saves the partition its first pass over the keys
+  __shared__ uint32_t lh0[1024];
+  if (hist0) {
+    for (uint32_t d = threadIdx.x; d < (1u << dig_bits); d += blockDim.x) lh0[d] = 0;
+    __syncthreads();
+  }
   __shared__ uint64_t ringG[SHK_HASH_WAVES][256];  // launched with at most SHK_HASH_WAVES waves per group
   __shared__ uint64_t ringH[SHK_HASH_WAVES][256];
   const uint64_t nreads = *nreads_p;
@@ -337,6 +345,10 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
           const uint64_t rv = shk_ror64(H1 ^ H0, rot_r);
           const uint64_t hv = fh < rv ? fh : rv;
           words[out + p] = (hv & mask) | chunk_tag;
+          if (hist0) {   // the digit exactly as k_rp_scatter computes it (shk_word_region)
+            const uint32_t reg = (uint32_t)((((hv & mask) >> 8) - q_lo) >> SHK_REGION_LOG2);
+            atomicAdd(&lh0[(reg >> dig_shift) & ((1u << dig_bits) - 1)], 1u);
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -345,5 +357,10 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
       if (e == len) break;
       s = e + 1;
     }
+  }
+  if (hist0) {
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < (1u << dig_bits); d += blockDim.x)
+      if (lh0[d]) atomicAdd((unsigned long long *)&hist0[d], (unsigned long long)lh0[d]);
   }
 }

@@ -335,8 +335,10 @@ static int parse_stage(shk_ctx *c, const void *text, int on_device, uint64_t tex
 }
 
 static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
-                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
-  // chunk i of this call is labelled chunk_first + i * chunk_mul
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul, bool hist0 = false) {
+  // chunk i of this call is labelled chunk_first + i * chunk_mul; hist0: the hash kernel also fills the first partition
+  // level's histogram (d_hist[0]), see partition_stage
+  if (hist0) HIPCHK(hipMemsetAsync(c->d_hist[0], 0, (1ULL << c->lv[0].bits) * 8, c->stream));
   if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
   const uint8_t *dtext;
   uint64_t nreads;
@@ -353,7 +355,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
     const uint32_t ht = c->threads < SHK_HASH_WAVES * SHK_WAVE ? c->threads : SHK_HASH_WAVES * SHK_WAVE;
     hipLaunchKernelGGL(k_hash_reads, dim3(groups * (c->threads / ht)), dim3(ht), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
                        c->d_scalars + 0, c->d_rd_chunk, chunk_first, chunk_mul, c->d_key_base, c->cfg.k, c->cfg.hb,
-                       c->d_words[0], c->cfg.max_batch_keys, c->d_err); }
+                       c->d_words[0], c->cfg.max_batch_keys, c->d_err, hist0 ? c->d_hist[0] : nullptr, c->lv[0].shift, c->lv[0].bits, c->q_lo); }
   HIPCHK(hipGetLastError());
   return SHK_OK;
 }
@@ -361,7 +363,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
 // words in d_words[src] (count in d_scalars[1], bound nmax) -> sorted by region in
 // d_words[*dst]; region offsets in d_base[nlevels]
 // (ext != null: the first level reads the caller's buffer instead of d_words[src])
-static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr) {
+static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr, bool hist0_ready = false) {
   const uint64_t *n_p = c->d_scalars + 1;
   { ProfScope ps(c, KP_RP_PREP);
     hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]); }
@@ -372,8 +374,8 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
     { ProfScope ps(c, KP_RP_PREP);
       hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
-      HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
-    { ProfScope ps(c, KP_RP_HIST);
+      if (!(l == 0 && hist0_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
+    if (!(l == 0 && hist0_ready)) { ProfScope ps(c, KP_RP_HIST);
       const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
       hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
     if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
@@ -789,7 +791,7 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   shk_batch_stats st;
   memset(&st, 0, sizeof(st));
   HIPCHK(hipSetDevice(c->dev));
-  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1);
+  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1, true);
   if (rc) return finish(c, rc);
   uint32_t bits = 0;
   HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -798,7 +800,7 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   const uint64_t nwords = c->h_pinned[42];
   if (nwords > c->cfg.max_batch_keys) { prof_collect(c); return SHK_ERR_BATCH; }
   int dst = 0;
-  rc = partition_stage(c, 0, nwords, &dst);
+  rc = partition_stage(c, 0, nwords, &dst, nullptr, true);   // the hash kernel already counted the first level's digits
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
