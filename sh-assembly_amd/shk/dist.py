@@ -5,6 +5,8 @@ key words it OWNS (routing is the caller's all-to-all), and the ranks take the d
 together on all-reduced statistics, so a round fires after the same global chunk on every
 shard -- the chunk at which the whole filter's distinct count reaches the trigger
 (cqf/CQF_mt.h:837, 860-869). Works with RCCL ("nccl") on GPUs and with gloo on the CPU."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -200,6 +202,10 @@ def route_words(ctx, nwords, hb, world, rank, device):
         outs = [recv[roff[p] + min(r0, rc[p]): roff[p] + min(r0 + ROUTE_PIECE, rc[p])] for p in range(world)]
         if world == 1:
             outs[0].copy_(ins[0])
+            continue
+        if device.type == "cuda" and not os.environ.get("SHK_A2A_SINGLE"):
+            # RCCL: grouped sends/receives straight between the bins and their places in `recv` (views, no staging copies)
+            dist.all_to_all(outs, ins)
             continue
         isz, osz = [int(x.numel()) for x in ins], [int(x.numel()) for x in outs]
         piece = torch.empty((sum(osz),), dtype=torch.int64, device=device)
