@@ -255,6 +255,14 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   }
   if (b0 + nblk_old > A.nblocks) nblk_old = (uint32_t)(A.nblocks - b0);
 
+  // A region without old runs and without words has nothing to say: T = 0, no statistics, all lengths 0
+  // (sparse tables -- the first batches of a build, big filters -- are mostly such regions)
+  if ((MODE == 0 || MODE == 3) && !old_any && !fatal && (!A.words || A.region_base[r] == A.region_base[r + 1])) {
+    if (tid < SHK_SUM_STRIDE) A.summary[(size_t)SHK_SUM_STRIDE * r + tid] = 0;
+    if (MODE == 3 && tid < SHK_WAVE) reinterpret_cast<uint32_t *>(A.spill + (size_t)r * SHK_SPILL_STRIDE)[tid] = 0;
+    return;
+  }
+
   // ---- stage the old bytes (dword copies; the region's first byte is 4-byte aligned)
   {
     const uint32_t nbytes = nblk_old * SHK_BLOCK_BYTES;
