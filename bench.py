@@ -200,9 +200,10 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: SHK_ABLATE bits applied to the timed steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/all-to-all code path even with one rank")
+    ap.add_argument("--host-text", action="store_true", help="hand the FASTQ text over in (pinned) host memory: PCIe-inclusive rate, never the headline value")
     args = ap.parse_args()
     default_workload = (args.reads_per_step == 8_000_000 and args.genome == 100_000_000 and args.qb == 0 and not args.ablate
-                        and args.gpus == 1)
+                        and args.gpus == 1 and not args.host_text)
 
     import torch
     import shk
@@ -239,7 +240,7 @@ def main():
     assert len(offs) <= shk.MAX_CHUNKS
 
     ctx = shk.Context(qb=qb, k=K, trigger=(trigger if not sharded else (1 << 62)), num_denoise=(nd if not sharded else 0),
-                      max_batch_bytes=64, max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
+                      max_batch_bytes=(R * (2 * L + NAME_W + 6) + 4096 if args.host_text else 64), max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
                       max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
     tot = ctx.totals()
 
@@ -249,6 +250,8 @@ def main():
     texts = [gen_batch_torch(torch, genome, R, L, ERR, (s * world + rank) * R, 1000 + s * world + rank, device)
              for s in range(nsteps)]
     torch.cuda.synchronize()
+    if args.host_text:
+        texts = [t.cpu().pin_memory() for t in texts]
 
     hb = qb + 8
     from shk import dist as shkdist
@@ -264,7 +267,7 @@ def main():
         nonlocal rounds_left, counted, removed_total, rounds_fired
         t = texts[s]
         if not sharded:
-            st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
+            st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=not args.host_text, text_bytes=t.numel())
             counted += st["kmers"]
             removed_total += st["removed"]
             rounds_fired += st["denoise_rounds"]

@@ -160,7 +160,7 @@ class Context:
     def count_chunks(self, text, chunk_off, chunk_len, on_device=False, text_bytes=None):
         """text: bytes (host) or an integer device pointer (on_device=True, text_bytes given)"""
         st = BatchStats()
-        if on_device:
+        if on_device or isinstance(text, int):      # an integer is a raw pointer (device, or host memory the caller keeps alive)
             ptr, n = C.c_void_p(int(text)), int(text_bytes)
         else:
             buf = (C.c_char * len(text)).from_buffer_copy(text) if not isinstance(text, C.Array) else text
