@@ -257,6 +257,7 @@ def main():
     from shk import dist as shkdist
     sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
     counted_global = [0]
+    uploaded = {}
     shard_shift = (qb - int(math.log2(world))) + 8
     rounds_left = nd
     counted = 0
@@ -267,7 +268,16 @@ def main():
         nonlocal rounds_left, counted, removed_total, rounds_fired
         t = texts[s]
         if not sharded:
-            st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=not args.host_text, text_bytes=t.numel())
+            if args.host_text:
+                # overlapped ingest: this batch's copy was started before the previous batch was counted
+                if s not in uploaded:
+                    uploaded[s] = ctx.upload_text(t.data_ptr(), t.numel())
+                dptr = uploaded.pop(s)
+                if s + 1 < nsteps:
+                    uploaded[s + 1] = ctx.upload_text(texts[s + 1].data_ptr(), texts[s + 1].numel())
+                st = ctx.count_chunks(dptr, offs, lens, on_device=True, text_bytes=t.numel())
+            else:
+                st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
             counted += st["kmers"]
             removed_total += st["removed"]
             rounds_fired += st["denoise_rounds"]

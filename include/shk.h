@@ -100,6 +100,11 @@ int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_
                      const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
                      shk_batch_stats *stats);
 
+/* Overlapped ingest: start copying host text (pinned memory for full PCIe rate) for a LATER call into one of two
+ * context-owned device buffers; the copy runs on its own stream while the context computes. Pass the returned
+ * pointer as `text` with text_on_device = 1; that call waits for the copy. Upload batch s+1, then count batch s. */
+int shk_upload_text(shk_ctx *ctx, const void *host_text, uint64_t nbytes, void **d_text);
+
 /* Hash only: leaves `*nwords` key words (key | chunk_index << hb, reference emission
  * order) in a context-owned device buffer `*d_words`, valid until the next call.
  * In a context that is one of G shards, chunk i of the call is labelled i * G + shard_index:

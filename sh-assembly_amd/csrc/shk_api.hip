@@ -52,6 +52,10 @@ struct shk_ctx {
   uint64_t *fin[2];
   int cur;                      // which of tab[]/fin[] is live
   uint8_t *d_text;
+  uint8_t *d_up[2];             // shk_upload_text: two alternating buffers filled on a copy stream
+  hipStream_t copy_stream;
+  hipEvent_t up_done[2];
+  int up_next, up_pending[2];
   uint64_t *d_chunk_off, *d_chunk_len, *d_nlines, *d_reads_base;
   uint64_t *d_rd_start, *d_rd_end;
   uint16_t *d_rd_chunk;         // chunk (within the call) of every read
@@ -258,6 +262,11 @@ extern "C" void shk_destroy(shk_ctx *c) {
   if (!c) return;
   hipSetDevice(c->dev);
   hipStreamSynchronize(c->stream);
+  if (c->copy_stream) {
+    hipStreamSynchronize(c->copy_stream);
+    for (int b = 0; b < 2; b++) { if (c->d_up[b]) hipFree(c->d_up[b]); if (c->up_done[b]) hipEventDestroy(c->up_done[b]); }
+    hipStreamDestroy(c->copy_stream);
+  }
   if (getenv("SHK_STAMPS")) {
     unsigned long long st[16];
     hipMemcpy(st, c->d_scalars + 16, sizeof(st), hipMemcpyDeviceToHost);
@@ -309,8 +318,11 @@ static int parse_stage(shk_ctx *c, const void *text, int on_device, uint64_t tex
   for (uint32_t i = 0; i < nchunks; i++)
     if (chunk_off[i] + chunk_len[i] > text_bytes) return SHK_ERR_ARG;
   const uint8_t *dtext;
-  if (on_device) dtext = (const uint8_t *)text;
-  else {
+  if (on_device) {
+    dtext = (const uint8_t *)text;
+    for (int b = 0; b < 2; b++)   // a buffer of shk_upload_text whose copy may still be running
+      if (c->d_up[b] && dtext == c->d_up[b] && c->up_pending[b]) { HIPCHK(hipStreamWaitEvent(c->stream, c->up_done[b], 0)); c->up_pending[b] = 0; }
+  } else {
     if (text_bytes > c->cfg.max_batch_bytes) return SHK_ERR_BATCH;
     HIPCHK(hipMemcpyAsync(c->d_text, text, text_bytes, hipMemcpyHostToDevice, c->stream));
     dtext = c->d_text;
@@ -805,6 +817,26 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
   return finish(c, rc);
+}
+
+// Start copying host text for a later call into one of two context-owned device buffers (they alternate). The copy
+// runs on its own stream, next to whatever the context is computing; the call that is handed the returned pointer
+// (text_on_device = 1) waits for it. A buffer is reused by the second-next upload, i.e. after the call that read it.
+extern "C" int shk_upload_text(shk_ctx *c, const void *host_text, uint64_t nbytes, void **d_text) {
+  if (!c || !host_text || !d_text || nbytes > c->cfg.max_batch_bytes) return c && host_text && d_text ? SHK_ERR_BATCH : SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) HIPCHK(hipEventCreateWithFlags(&c->up_done[b], hipEventDisableTiming));
+  }
+  const int b = c->up_next;
+  if (!c->d_up[b] && dmalloc(&c->d_up[b], c->cfg.max_batch_bytes + 64)) return SHK_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(c->d_up[b], host_text, nbytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(hipEventRecord(c->up_done[b], c->copy_stream));
+  c->up_pending[b] = 1;
+  c->up_next ^= 1;
+  *d_text = c->d_up[b];
+  return SHK_OK;
 }
 
 extern "C" int shk_hash_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes,

@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -83,6 +83,7 @@ def load(path=None):
     L.shk_destroy.restype = None
     L.shk_count_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(BatchStats)]
     L.shk_hash_chunks.argtypes = [vp, vp, i32, u64, pu64, pu64, u32, C.POINTER(vp), pu64]
+    L.shk_upload_text.argtypes = [vp, vp, u64, C.POINTER(vp)]
     L.shk_count_words.argtypes = [vp, vp, u64, u32, C.POINTER(BatchStats)]
     L.shk_route_words.argtypes = [vp, u64, u32, C.POINTER(vp), pu64]
     L.shk_stage_words.argtypes = [vp, vp, u64]
@@ -168,6 +169,12 @@ class Context:
         self._chk(self.L.shk_count_chunks(self.h, ptr, 1 if on_device else 0, n, self._tab(chunk_off),
                                           self._tab(chunk_len), len(chunk_off), C.byref(st)))
         return st.as_dict()
+
+    def upload_text(self, host_ptr, nbytes):
+        """start the copy of host text for a later count_chunks(..., on_device=True); returns the device pointer"""
+        dp = C.c_void_p()
+        self._chk(self.L.shk_upload_text(self.h, C.c_void_p(int(host_ptr)), int(nbytes), C.byref(dp)))
+        return dp.value
 
     def hash_chunks(self, text, chunk_off, chunk_len, on_device=False, text_bytes=None):
         """returns (device pointer, nwords)"""

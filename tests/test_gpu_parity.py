@@ -431,3 +431,32 @@ def test_region_hash_overflow_halves_the_chunk_range():
         ctx.count_words(t2.data_ptr(), t2.numel(), 1)
     assert ctx.blocks() == want
     ctx.close()
+
+
+def test_overlapped_upload_matches_oracle():
+    """shk_upload_text: batches copied on the context's copy stream while the previous batch is counted; three
+    batches through the two alternating buffers give the oracle's table"""
+    import ctypes as C
+    qb, k = 19, 47
+    g = synth.make_genome(20000, 3)
+    fqs = [synth.make_fastq(g, 900, 150, 0.01, seed=40 + i, name_prefix="b%d_" % i) for i in range(3)]
+    tabs = [chunks_by_records(fq, 300) for fq in fqs]
+    bufs = [C.create_string_buffer(fq, len(fq)) for fq in fqs]
+    ctx = _ctx(qb=qb, k=k, max_batch_bytes=max(len(fq) for fq in fqs) + 1024, max_batch_keys=900 * 150)
+    nxt = ctx.upload_text(C.addressof(bufs[0]), len(fqs[0]))
+    for i in range(3):
+        cur = nxt
+        if i + 1 < 3:
+            nxt = ctx.upload_text(C.addressof(bufs[i + 1]), len(fqs[i + 1]))
+        ctx.count_chunks(cur, tabs[i][0], tabs[i][1], on_device=True, text_bytes=len(fqs[i]))
+    whole = b"".join(fqs)
+    offs, lens, base = [], [], 0
+    for fq, (o, l) in zip(fqs, tabs):
+        offs += [base + x for x in o]
+        lens += l
+        base += len(fq)
+    q, _, _ = oracle_t1(whole, offs, lens, k, qb)
+    assert not q.full()
+    assert ctx.blocks() == q.blocks()
+    ctx.close()
+    q.free()
