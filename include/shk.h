@@ -104,6 +104,9 @@ int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_
  * context-owned device buffers; the copy runs on its own stream while the context computes. Pass the returned
  * pointer as `text` with text_on_device = 1; that call waits for the copy. Upload batch s+1, then count batch s. */
 int shk_upload_text(shk_ctx *ctx, const void *host_text, uint64_t nbytes, void **d_text);
+/* page-locked host memory for the text handed to shk_upload_text (pageable memory works, at a fraction of the rate) */
+int shk_host_alloc(uint64_t nbytes, void **p);
+void shk_host_free(void *p);
 
 /* Hash only: leaves `*nwords` key words (key | chunk_index << hb, reference emission
  * order) in a context-owned device buffer `*d_words`, valid until the next call.

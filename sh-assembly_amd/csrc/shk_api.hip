@@ -839,6 +839,14 @@ extern "C" int shk_upload_text(shk_ctx *c, const void *host_text, uint64_t nbyte
   return SHK_OK;
 }
 
+// page-locked host memory for shk_upload_text sources (callers that do not link the HIP runtime themselves)
+extern "C" int shk_host_alloc(uint64_t nbytes, void **p) {
+  if (!p) return SHK_ERR_ARG;
+  HIPCHK(hipHostMalloc(p, nbytes, hipHostMallocDefault));
+  return SHK_OK;
+}
+extern "C" void shk_host_free(void *p) { if (p) hipHostFree(p); }
+
 extern "C" int shk_hash_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes,
                                const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
                                uint64_t **d_words, uint64_t *nwords) {

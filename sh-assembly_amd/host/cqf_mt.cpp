@@ -2,7 +2,10 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 #include <iostream>
+#include <mutex>
+#include <thread>
 
 namespace shk {
 
@@ -26,30 +29,85 @@ void CQF_mt::build_KmerSpectrum(const std::vector<std::string> &fnames, const FI
   const uint64_t max_bytes = (uint64_t)parts_per_call * (part_size + overhead);
   ensure_ctx(ksize, n_distinct_elts_for_DeNoise, n_deNoise, max_bytes);
   seqFile_batch files(fnames, ftype, fmode, part_size, overhead);
-  std::vector<char> text;
-  std::vector<uint64_t> off, len;
-  text.reserve(max_bytes);
-  auto flush = [&]() {
-    shk_batch_stats st;
-    chk(shk_count_chunks(ctx, text.data(), 0, text.size(), off.data(), len.data(), (uint32_t)off.size(), &st));
-    for (uint32_t r = 0; r < st.denoise_rounds; r++) {
-      // CQF_mt.h:868/912 print these lines around every round
-      std::cerr << "Finished DeNoise: ndistinct_elts/total_elts." << ndistinct_elts() << "/" << nelts() << std::endl;
+  // Three page-locked batch buffers rotate: a reader thread fills one from the files while the copy of the
+  // previous one runs on the context's copy stream (shk_upload_text) and the batch before that is counted.
+  // The parts reach the filter in exactly the order the single-threaded loop would present them.
+  struct Batch { char *text = nullptr; uint64_t bytes = 0; std::vector<uint64_t> off, len; bool last = false; };
+  Batch ring[3];
+  for (auto &bt : ring) { void *p = nullptr; chk(shk_host_alloc(max_bytes + 64, &p)); bt.text = (char *)p; }
+  std::mutex mu;
+  std::condition_variable cv;
+  int filled = 0, taken = 0;          // batches produced / consumed (ring slot = index % 3)
+  bool reader_bad = false;
+  std::thread reader([&]() {
+    chunk c;
+    bool more = true;
+    while (more) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled - taken < 3; }); }
+      Batch &bt = ring[filled % 3];
+      bt.bytes = 0; bt.off.clear(); bt.len.clear(); bt.last = false;
+      while (bt.off.size() < parts_per_call) {
+        if (!files.getDataChunk(c)) { more = false; break; }
+        bt.off.push_back(bt.bytes);
+        bt.len.push_back(c.get_size());
+        memcpy(bt.text + bt.bytes, c.get_reads(), c.get_size());
+        bt.bytes += c.get_size();
+        free(c.get_reads());
+      }
+      bt.last = !more;
+      if (files.bad()) reader_bad = true;
+      { std::lock_guard<std::mutex> lk(mu); filled++; }
+      cv.notify_all();
     }
-    denoise_rounds_done += st.denoise_rounds;
-    removed_total += st.removed;
-    text.clear(); off.clear(); len.clear();
+  });
+  auto pop = [&]() -> Batch * {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return filled > taken; });
+    return &ring[taken % 3];
   };
-  chunk c;
-  while (files.getDataChunk(c)) {
-    off.push_back(text.size());
-    len.push_back(c.get_size());
-    text.insert(text.end(), c.get_reads(), c.get_reads() + c.get_size());
-    free(c.get_reads());
-    if (off.size() == parts_per_call) flush();
+  auto release = [&]() { { std::lock_guard<std::mutex> lk(mu); taken++; } cv.notify_all(); };
+  std::string err;
+  try {
+    Batch *cur = pop();
+    void *dcur = nullptr;
+    if (cur->bytes) chk(shk_upload_text(ctx, cur->text, cur->bytes, &dcur));
+    for (;;) {
+      Batch *nxt = nullptr;
+      void *dnxt = nullptr;
+      if (!cur->last) {
+        // the next batch is ring[(taken + 1) % 3]: wait for it and start its copy before counting the current one
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return filled > taken + 1; }); }
+        nxt = &ring[(taken + 1) % 3];
+        if (nxt->bytes) chk(shk_upload_text(ctx, nxt->text, nxt->bytes, &dnxt));
+      }
+      if (!cur->off.empty()) {
+        shk_batch_stats st;
+        chk(shk_count_chunks(ctx, dcur, 1, cur->bytes, cur->off.data(), cur->len.data(), (uint32_t)cur->off.size(), &st));
+        for (uint32_t r = 0; r < st.denoise_rounds; r++) {
+          // CQF_mt.h:868/912 print these lines around every round
+          std::cerr << "Finished DeNoise: ndistinct_elts/total_elts." << ndistinct_elts() << "/" << nelts() << std::endl;
+        }
+        denoise_rounds_done += st.denoise_rounds;
+        removed_total += st.removed;
+      }
+      const bool was_last = cur->last;
+      release();
+      if (was_last) break;
+      cur = nxt; dcur = dnxt;
+    }
+  } catch (const std::exception &e) {
+    err = e.what();
+    // let the reader run to the end of the files so that it can be joined
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      if (filled > taken) { const bool l = ring[taken % 3].last; taken++; lk.unlock(); cv.notify_all(); if (l) break; }
+      else cv.wait(lk, [&] { return filled > taken; });
+    }
   }
-  if (files.bad()) throw std::runtime_error("Error: Wrong input file!");
-  if (!off.empty()) flush();
+  reader.join();
+  for (auto &bt : ring) shk_host_free(bt.text);
+  if (!err.empty()) throw std::runtime_error(err);
+  if (reader_bad || files.bad()) throw std::runtime_error("Error: Wrong input file!");
   if (end_deNoise) {   // CQF_mt.h:860: one more round after the last part, not counted in n_deNoise
     uint64_t removed = 0;
     chk(shk_denoise(ctx, &removed));

@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
