@@ -161,6 +161,10 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline double emu_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent(); return 0; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 1; return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new EmuEvent(); return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
