@@ -1,9 +1,34 @@
 #include "fastq_chunker.hpp"
 
+#include <dlfcn.h>
+
 #include <stdlib.h>
 #include <string.h>
 
 namespace shk {
+
+// libbz2's stream-reading interface (bzlib.h: BZ2_bzReadOpen / BZ2_bzRead / BZ2_bzReadClose), bound with dlopen: the
+// image ships the library but not its header. The reference calls the same three functions (cqf/CQF_mt.h:756, 948).
+struct Bz2Api {
+  void *(*read_open)(int *bzerror, FILE *f, int verbosity, int small, void *unused, int nunused);
+  int (*read)(int *bzerror, void *b, void *buf, int len);
+  void (*read_close)(int *bzerror, void *b);
+};
+static const Bz2Api *bz2_api() {
+  static Bz2Api api;
+  static int state = 0;   // 0 untried, 1 ok, -1 missing
+  if (state == 0) {
+    void *h = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW);
+    if (h) {
+      api.read_open = (decltype(api.read_open))dlsym(h, "BZ2_bzReadOpen");
+      api.read = (decltype(api.read))dlsym(h, "BZ2_bzRead");
+      api.read_close = (decltype(api.read_close))dlsym(h, "BZ2_bzReadClose");
+    }
+    state = (h && api.read_open && api.read && api.read_close) ? 1 : -1;
+  }
+  return state == 1 ? &api : nullptr;
+}
 
 seqFile_batch::seqFile_batch(const std::vector<std::string> &file_names, FILE_TYPE, FILE_MODE fm, uint64_t part_size,
                              uint32_t overhead)
@@ -19,8 +44,13 @@ seqFile_batch::seqFile_batch(const std::vector<std::string> &file_names, FILE_TY
       if (!fp->in_gzip) continue;
       gzbuffer(fp->in_gzip, 1u << 26);
     } else {
-      fprintf(stderr, "bzip2 input is not available in this build (no bzlib.h in the image)\n");
-      continue;
+      // cqf/CQF_mt.h:944-954: FILE* + BZ2_bzReadOpen
+      if (!bz2_api()) { fprintf(stderr, "bzip2 input needs libbz2.so.1.0 at run time (not found)\n"); continue; }
+      fp->in = fopen(fname.c_str(), "rb");
+      if (!fp->in) continue;
+      setvbuf(fp->in, NULL, _IOFBF, 1u << 26);
+      fp->in_bzip2 = bz2_api()->read_open(&fp->bzerror, fp->in, 0, 0, NULL, 0);
+      if (!fp->in_bzip2) { fclose(fp->in); fp->in = nullptr; continue; }
     }
     fp->part_buffer.resize(overhead_ + part_size_);
     files_.push_back(std::move(fp));
@@ -29,6 +59,7 @@ seqFile_batch::seqFile_batch(const std::vector<std::string> &file_names, FILE_TY
 
 seqFile_batch::~seqFile_batch() {
   for (auto &fp : files_) {
+    if (fp->in_bzip2) { int e; bz2_api()->read_close(&e, fp->in_bzip2); }
     if (fp->in) fclose(fp->in);
     if (fp->in_gzip) gzclose(fp->in_gzip);
   }
@@ -37,6 +68,7 @@ seqFile_batch::~seqFile_batch() {
 bool seqFile_batch::is_eof(file_pointer *fp) const {   // cqf/CQF_mt.h:561-570
   if (fp->fmode == TEXT) return feof(fp->in) != 0;
   if (fp->fmode == GZIP) return gzeof(fp->in_gzip) != 0;
+  if (fp->fmode == BZIP2) return fp->bzerror == 4;   // BZ_STREAM_END
   return true;
 }
 
@@ -58,6 +90,7 @@ bool seqFile_batch::read_part(file_pointer *fp, chunk &out) {
   uint64_t readed = 0;
   if (fp->fmode == TEXT) readed = fread(part + fp->part_filled, 1, part_size_, fp->in);
   else if (fp->fmode == GZIP) { int r = gzread(fp->in_gzip, part + fp->part_filled, (unsigned)part_size_); readed = r > 0 ? (uint64_t)r : 0; }
+  else if (fp->fmode == BZIP2) { int r = bz2_api()->read(&fp->bzerror, fp->in_bzip2, part + fp->part_filled, (int)part_size_); readed = r > 0 ? (uint64_t)r : 0; }
   const int64_t total_filled = (int64_t)(fp->part_filled + readed);
   if (fp->part_filled >= overhead_) {
     fprintf(stderr, "Error: Wrong input file!\n");
@@ -101,6 +134,7 @@ bool seqFile_batch::getDataChunk(chunk &data) {
       files_.push_back(std::move(fp));
       return true;
     }
+    if (fp->in_bzip2) { int e; bz2_api()->read_close(&e, fp->in_bzip2); fp->in_bzip2 = nullptr; }
     if (fp->in) { fclose(fp->in); fp->in = nullptr; }
     if (fp->in_gzip) { gzclose(fp->in_gzip); fp->in_gzip = nullptr; }
     if (bad_) return false;

@@ -26,6 +26,8 @@ struct chunk {                              // cqf/chunk.h:23-41 (the part of it
 struct file_pointer {                       // cqf/CQF_mt.h:324-331
   FILE *in = nullptr;
   gzFile in_gzip = nullptr;
+  void *in_bzip2 = nullptr;                 // BZFILE* (libbz2 is bound at run time, see fastq_chunker.cpp)
+  int bzerror = 0;
   std::vector<char> part_buffer;            // carry-over between parts
   FILE_MODE fmode = TEXT;
   uint64_t part_filled = 0;

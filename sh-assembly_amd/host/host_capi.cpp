@@ -14,7 +14,7 @@ extern "C" {
 uint64_t shkh_chunk_sizes(const char **paths, int nfiles, int mode, uint64_t part_size, uint32_t overhead, uint64_t *sizes,
                           uint64_t cap) {
   std::vector<std::string> f(paths, paths + nfiles);
-  shk::seqFile_batch b(f, shk::FASTQ, mode ? shk::GZIP : shk::TEXT, part_size, overhead);
+  shk::seqFile_batch b(f, shk::FASTQ, mode == 1 ? shk::GZIP : mode == 2 ? shk::BZIP2 : shk::TEXT, part_size, overhead);
   shk::chunk c;
   uint64_t n = 0;
   while (b.getDataChunk(c)) { if (n < cap) sizes[n] = c.get_size(); n++; free(c.get_reads()); }

@@ -67,7 +67,7 @@ def _hostlib():
 
 def test_cpp_chunker_matches_oracle(tmp_path):
     """sh-assembly_amd/host/fastq_chunker.cpp (seqFile_batch) against the oracle chunker and the
-    golden chunk sizes; round robin over two files; gzip == plain"""
+    golden chunk sizes; round robin over two files; gzip == bzip2 == plain"""
     import ctypes as C
     import gzip
     import json
@@ -97,6 +97,11 @@ def test_cpp_chunker_matches_oracle(tmp_path):
     with gzip.open(gz, "wb") as g:
         g.write(open(f0, "rb").read())
     assert sizes([gz], 1, 20000, 4095) == a
+    import bz2
+    bz = str(tmp_path / "r0.fq.bz2")
+    with bz2.open(bz, "wb") as g:
+        g.write(open(f0, "rb").read())
+    assert sizes([bz], 2, 20000, 4095) == a          # bzip2 through libbz2's BZ2_bzRead, as the reference reads it
 
 
 def test_cpp_sizing_matches_oracle():
