@@ -156,6 +156,11 @@ int shk_stage_commit(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, const s
 int shk_stage_try(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                   int want_hist, shk_summary *out);
 int shk_stage_accept(shk_ctx *ctx, const shk_summary *s);
+/* One deNoise round on this shard fused with the insertion of the staged chunks [lo, hi] that lie behind the deNoise
+ * point (one pass over the table instead of two): statistics only; shk_stage_accept writes. out->removed = singletons
+ * dropped; a dropped key that reappears in [lo, hi] counts in out->new_distinct. If any rank reports err_bits, or the
+ * trigger would be reached again inside [lo, hi], do not accept: run shk_denoise and go on as usual. */
+int shk_stage_try_denoise(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, shk_summary *out);
 /* want_hist = 2 in shk_stage_summary / shk_stage_try additionally records the first chunk of every
  * new key; this call returns the exact histogram of that last pass: out[i] = new keys first seen in
  * chunk i, for i < n (n <= chunk_hi + 1 of the pass). With it the ranks find the chunk of a deNoise

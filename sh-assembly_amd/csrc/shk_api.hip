@@ -995,11 +995,35 @@ extern "C" int shk_stage_accept(shk_ctx *c, const shk_summary *s) {
   if (c->single_ok) commit_single(c);
   else {
     if (!c->spill_valid) return SHK_ERR_ARG;   // nothing was tried
-    int rc = merge_write(c, c->spill_words, c->spill_lo, c->spill_hi, 0);
+    const int dn = c->spill_denoise;
+    int rc = merge_write(c, c->spill_words, c->spill_lo, c->spill_hi, dn);
     if (rc) return finish(c, rc);
+    if (dn) { c->big_image = 0; c->rounds_done++; }
   }
   c->ndistinct += s->new_distinct; c->nelts += s->added;
+  c->ndistinct -= s->removed; c->nelts -= s->removed;     // (only a deNoise try removes anything)
   return finish(c, SHK_OK);
+}
+
+// deNoise round on this shard fused with the insertion of the staged chunks [lo, hi] (the chunks behind the deNoise
+// point): marks + statistics pass; nothing is written until shk_stage_accept. s->removed = singletons dropped,
+// s->new_distinct counts dropped keys that reappear in [lo, hi] as new. Needs the spill scheme (default).
+extern "C" int shk_stage_try_denoise(shk_ctx *c, uint32_t lo, uint32_t hi, shk_summary *out) {
+  if (!c || !out || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (!c->use_spill) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
+  { ProfScope ps(c, KP_MARKS);
+    hipLaunchKernelGGL(k_denoise_marks, dim3(1), dim3(64), 0, c->stream, c->tab[c->cur], c->nslots, c->xnslots, c->nblocks,
+                       ml, (unsigned long long *)(c->d_scalars + 3)); }
+  MergeOut o;
+  int rc = merge_summary(c, c->d_words[c->staged], lo, hi, lo, 0, 1, &o, 0, 1);
+  prof_collect(c);
+  if (rc) return rc;
+  out->new_distinct = o.newd; out->added = o.added; out->removed = o.removed; out->before = o.before;
+  for (int i = 0; i < SHK_HIST_BINS; i++) out->hist[i] = o.hist[i];
+  out->err_bits = o.err; out->reserved = 0;
+  return SHK_OK;
 }
 
 extern "C" int shk_stage_chunk_hist(shk_ctx *c, uint64_t *out, uint32_t n) {

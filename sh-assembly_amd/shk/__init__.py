@@ -59,7 +59,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -91,6 +91,7 @@ def load(path=None):
     L.shk_stage_commit.argtypes = [vp, u32, u32, C.POINTER(Summary)]
     L.shk_stage_try.argtypes = [vp, u32, u32, u32, u32, i32, C.POINTER(Summary)]
     L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
+    L.shk_stage_try_denoise.argtypes = [vp, u32, u32, C.POINTER(Summary)]
     L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
     L.shk_extend_forward.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32, u64, i32, u32, C.c_char_p, C.POINTER(u32),
                                      C.POINTER(u32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(u32)]
@@ -246,6 +247,11 @@ class Context:
         self._chk(self.L.shk_find_unitigs(self.h, b"".join(seeds), sc, n, k, abundance_min, max_len, out_path.encode(),
                                           C.cast(st, C.c_void_p)))
         return dict(zip(("unitigs", "total_len", "rounds", "extensions", "duplicates", "truncated"), list(st)))
+
+    def stage_try_denoise(self, lo, hi):
+        s = Summary()
+        self._chk(self.L.shk_stage_try_denoise(self.h, lo, hi, C.byref(s)))
+        return s
 
     def stage_accept(self, summary):
         self._chk(self.L.shk_stage_accept(self.h, C.byref(summary)))

@@ -150,11 +150,29 @@ def sharded_count(ctx, st, nchunks):
         if fire:
             st.rounds_left -= 1
             st.rounds_done += 1
-            removed = _allreduce([ctx.denoise()], st.device)[0]
-            st.ndistinct -= removed
-            st.nelts -= removed
-            out["removed"] += removed
             out["denoise_rounds"] += 1
+            fused = False
+            if hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
+                # one pass: drop the singletons and insert the chunks behind the deNoise point; taken when no rank
+                # objects and the trigger is not reached again inside the rest
+                loc = ctx.stage_try_denoise(hi + 1, nchunks - 1)
+                red = _allreduce([loc.new_distinct, loc.removed, loc.added], st.device)
+                bad = _allreduce([1 if loc.err_bits else 0], st.device, dist.ReduceOp.MAX)[0]
+                again = st.rounds_left > 0 and st.ndistinct - red[1] + red[0] >= st.trigger
+                if not bad and not again:
+                    ctx.stage_accept(loc)
+                    st.ndistinct += red[0] - red[1]
+                    st.nelts += red[2] - red[1]
+                    out["removed"] += red[1]
+                    out["kmers"] += red[2]
+                    out["new_distinct"] += red[0]
+                    fused = True
+                    hi = nchunks - 1
+            if not fused:
+                removed = _allreduce([ctx.denoise()], st.device)[0]
+                st.ndistinct -= removed
+                st.nelts -= removed
+                out["removed"] += removed
         lo = hi + 1
     return out
 
