@@ -58,10 +58,13 @@ static inline void set_runw(orc_qf *qf, uint64_t b, uint64_t v) { st64(qf->block
 static inline void set_travw(orc_qf *qf, uint64_t b, uint64_t v) { st64(qf->blocks + b * ORC_BLOCK_BYTES + 17, v); }
 static inline uint8_t *slotp(const orc_qf *qf, uint64_t i) { return qf->blocks + (i / 64) * ORC_BLOCK_BYTES + 25 + (i % 64); }
 static inline uint64_t get_slot(const orc_qf *qf, uint64_t i) { return *slotp(qf, i); }          /* gqf.c:542 */
-static inline void set_slot(orc_qf *qf, uint64_t i, uint64_t v) { *slotp(qf, i) = (uint8_t)v; } /* gqf.c:556 */
+/* writes behind the table happen only once an insert has found it full (qf->full is set; the result is void and the
+ * tests discard it) -- the reference would overrun here; the oracle must stay inside its allocation */
+static inline void set_slot(orc_qf *qf, uint64_t i, uint64_t v) { if (i / 64 <= qf->nblocks) *slotp(qf, i) = (uint8_t)v; } /* gqf.c:556 */
 static inline int is_runend(const orc_qf *qf, uint64_t i) { return (runw(qf, i / 64) >> (i % 64)) & 1; }   /* :474 */
 static inline int is_occupied(const orc_qf *qf, uint64_t i) { return (occw(qf, i / 64) >> (i % 64)) & 1; } /* :480 */
 static inline void set_runend(orc_qf *qf, uint64_t i, int v) {
+  if (i / 64 > qf->nblocks) return;
   uint64_t w = runw(qf, i / 64);
   if (v) w |= 1ULL << (i % 64); else w &= ~(1ULL << (i % 64));
   set_runw(qf, i / 64, w);

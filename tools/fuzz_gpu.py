@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU: many small random configurations (filter size, k, read mix, chunking, batching,
+deNoise trigger/rounds/min length) through shk_count_chunks against the oracle's t = 1 build. Prints failures."""
+import argparse, os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sh-assembly_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import torch  # noqa: F401  (torch's HIP runtime first)
+    import shk, synth
+    from fastq_util import chunks_by_records, oracle_t1, oracle_header
+    rnd = random.Random(args.seed)
+    bad = 0
+    t0 = time.time()
+    for case in range(args.cases):
+        qb = rnd.choice([11, 12, 13, 14, 15, 16, 17])
+        k = rnd.choice([21, 28, 31, 47, 63, 64, 65, 100])
+        L = rnd.choice([max(k + 5, 60), 100, 150])
+        cap = int((1 << qb) * 0.45)
+        nreads = max(8, min(4000, cap // max(1, (L - k + 1)) * rnd.choice([1, 2, 3])))
+        G = max(200, nreads * L // rnd.choice([8, 20, 40]))
+        err = rnd.choice([0.0, 0.003, 0.01, 0.03])
+        fq = synth.make_fastq(synth.make_genome(G, rnd.randrange(1 << 30)), nreads, L, err, seed=rnd.randrange(1 << 30),
+                              n_frac=rnd.choice([0.0, 0.02, 0.2]), short_frac=rnd.choice([0.0, 0.05]), lower_frac=rnd.choice([0.0, 0.05]))
+        per = max(1, nreads // rnd.choice([1, 3, 7, 20]))
+        offs, lens = chunks_by_records(fq, per)
+        nd = rnd.choice([0, 1, 2, 3, 6])
+        trig = rnd.choice([cap // 8, cap // 4, cap // 2, cap])
+        endd = rnd.random() < 0.3
+        ml = rnd.choice([1 << 20, 1 << 10, 64])
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("case", case, dict(qb=qb, k=k, L=L, nreads=nreads, G=G, err=err, per=per, nd=nd, trig=trig, endd=endd, ml=ml), flush=True)
+        q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, trig, nd, endd, ml)
+        if q.full():
+            q.free()
+            continue
+        ctx = shk.Context(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024,
+                          max_batch_keys=nreads * L + 64)
+        ncalls = rnd.choice([1, 2, 3, len(offs)])
+        step = max(1, (len(offs) + ncalls - 1) // ncalls)
+        rounds = removed = 0
+        try:
+            for i in range(0, len(offs), step):
+                st = ctx.count_chunks(fq, offs[i:i + step], lens[i:i + step])
+                rounds += st["denoise_rounds"]; removed += st["removed"]
+            if endd:
+                removed += ctx.denoise(); rounds += 1
+            t = ctx.totals()
+            ok = ((rounds, removed) == (orounds, oremoved) and (t.nelts, t.ndistinct) == (q.nelts(), q.ndistinct())
+                  and ctx.blocks() == q.blocks() and ctx.header() == oracle_header(q))
+        except shk.ShkError as e:
+            ok = False
+            print("case", case, "error", e)
+        if not ok:
+            bad += 1
+            print("MISMATCH case", case, dict(qb=qb, k=k, L=L, nreads=nreads, G=G, err=err, per=per, nd=nd, trig=trig, endd=endd, ml=ml,
+                                              ncalls=ncalls, rounds=(rounds, orounds), removed=(removed, oremoved)))
+        ctx.close()
+        q.free()
+    print(f"fuzz: {args.cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+if __name__ == "__main__":
+    main()
