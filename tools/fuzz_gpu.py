@@ -9,10 +9,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sharded", action="store_true", help="drive the collective flow (shk/dist.py) with one rank over RCCL")
     args = ap.parse_args()
     import torch  # noqa: F401  (torch's HIP runtime first)
     import shk, synth
     from fastq_util import chunks_by_records, oracle_t1, oracle_header
+    if args.sharded:
+        import torch.distributed as dist
+        from shk import dist as shkdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ["SHK_A2A_NO_BYPASS"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        dev = torch.device("cuda:0")
     rnd = random.Random(args.seed)
     bad = 0
     t0 = time.time()
@@ -38,14 +46,25 @@ def main():
         if q.full():
             q.free()
             continue
-        ctx = shk.Context(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024,
-                          max_batch_keys=nreads * L + 64)
+        if args.sharded:
+            ctx = shk.Context(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L + 64,
+                              shard_index=0, num_shards=1)
+            sst = shkdist.ShardState(trig, nd, dev)
+        else:
+            ctx = shk.Context(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024,
+                              max_batch_keys=nreads * L + 64)
         ncalls = rnd.choice([1, 2, 3, len(offs)])
         step = max(1, (len(offs) + ncalls - 1) // ncalls)
         rounds = removed = 0
         try:
             for i in range(0, len(offs), step):
-                st = ctx.count_chunks(fq, offs[i:i + step], lens[i:i + step])
+                if args.sharded:
+                    _, nw = ctx.hash_chunks(fq, offs[i:i + step], lens[i:i + step])
+                    recv = shkdist.route_words(ctx, nw, qb + 8, 1, 0, dev)
+                    ctx.stage_words(recv.data_ptr(), recv.numel())
+                    st = shkdist.sharded_count(ctx, sst, len(offs[i:i + step]))
+                else:
+                    st = ctx.count_chunks(fq, offs[i:i + step], lens[i:i + step])
                 rounds += st["denoise_rounds"]; removed += st["removed"]
             if endd:
                 removed += ctx.denoise(); rounds += 1
@@ -62,6 +81,8 @@ def main():
         ctx.close()
         q.free()
     print(f"fuzz: {args.cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+    if args.sharded:
+        dist.destroy_process_group()
     sys.exit(1 if bad else 0)
 
 if __name__ == "__main__":
