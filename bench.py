@@ -4,9 +4,13 @@
 One "step" = one pass of the hot path (shk_count_chunks: FASTQ text resident in HBM ->
 ntHash keys -> region partition -> CQF rebuild, deNoise rounds included where the
 reference's t = 1 schedule fires them) over one batch of synthetic reads.
-Workload at N = 1: BASELINE.json configs[1] scaled to a few steps -- C. elegans-like
-100 Mbp uniform-random genome, 150 bp reads, e = 0.00234, k = 47, filter sized exactly as
-the README example (qb = 29, hb = 37, 0.70 GiB table, trigger ~3.1e8 distinct k-mers).
+The timed region is ONE CLEAN BUILD: `--steps` batches into an empty filter, so
+`build_time_s` is the BASELINE "CQF build time" for steps x 832 M k-mers (20 steps =
+16.6 G k-mers = the README's C. elegans data set, BASELINE.json configs[1]); warm-up
+steps run on a scratch filter of the same geometry. The build's command line follows the
+README recipe (-N = the k-mers presented, -n = the genome's k-mers, -e = the generator's
+error rate, sizing as src/CQF-deNoise.cpp:96-161) and is checked against a model of the
+filter's occupancy before it runs (sh-assembly_amd/shk/plan.py, tests/test_plan.py).
 
 N > 1 (driver launches via torch.distributed.run): the filter is sharded by quotient
 range, every rank hashes its own batch, bins the key words by owner and exchanges them
@@ -34,60 +38,9 @@ OVERHEAD = 65535                  # CQF_mt.h:742
 
 
 def sizing(K, n_true, N_total, alpha, fr=0.0):
-    """src/CQF-deNoise.cpp:96-161 (host arithmetic; Poisson CDF from scipy instead of boost)"""
-    from scipy.stats import poisson
-    num_true = int(N_total * (1 - alpha) ** K)
-    num_false = N_total - num_true
-    if not fr:
-        fr = 1.0 / n_true
-    mean = float(num_true // n_true)
-    cdf0 = poisson.cdf(0, mean)
-
-    def cdfp(x):
-        return (poisson.cdf(x, mean) - cdf0) / (1 - cdf0)
-    start, end = 0, int(mean + 1)
-    while cdfp(end) < fr:
-        end *= 2
-    nd = None
-    while start <= end:
-        if start == end:
-            nd = start
-            break
-        if start + 1 == end:
-            t1, t2 = cdfp(start), cdfp(end)
-            nd = end if t2 <= fr else (start if t1 <= fr else max(start - 1, 0))
-            break
-        mid = (start + end) // 2
-        c = cdfp(mid)
-        if c < fr:
-            start = mid + 1
-        elif c > fr:
-            end = mid - 1
-        else:
-            nd = start
-            break
-    if nd is None:
-        nd = start
-    enc, tmp = 0, num_true // n_true + 1
-    while tmp:
-        tmp >>= 7
-        enc += 1
-
-    def nslots(d):
-        return int(n_true * (enc + 1.5) + num_false * 10 // ((d + 1) * 9))
-    num_slots = nslots(nd)
-    qb, base = 1, 2
-    while base < num_slots:
-        qb += 1
-        base <<= 1
-    st = num_slots
-    while nd and st < (1 << qb):
-        nd -= 1
-        st = nslots(nd)
-    if st >= (1 << qb):
-        nd += 1
-    trigger = n_true + num_false // (nd + 1)
-    return qb, nd, trigger
+    """src/CQF-deNoise.cpp:96-161 (host arithmetic; Poisson CDF from scipy instead of boost): shk/plan.py"""
+    from shk import plan
+    return plan.sizing(K, n_true, N_total, alpha, fr)
 
 
 def chunk_table(nrec, rec, part=PART, overhead=OVERHEAD):
@@ -194,22 +147,24 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads-per-step", type=int, default=8_000_000)
-    ap.add_argument("--genome", type=int, default=119_157_843, help="synthetic genome length = distinct true k-mers n (README.md:91)")
-    ap.add_argument("--qb", type=int, default=0, help="override the filter size (default: README sizing)")
+    ap.add_argument("--genome", type=int, default=119_157_843, help="synthetic genome length (its G-K+1 k-mers are the distinct true k-mers, README.md:91)")
+    ap.add_argument("--qb", type=int, default=0, help="override the filter size (default: the reference's sizing)")
+    ap.add_argument("--max-load", type=float, default=0.95, help="predicted peak load above which deNoise rounds are added to the formula's (shk/plan.py)")
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: SHK_ABLATE bits applied to the timed steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/all-to-all code path even with one rank")
-    ap.add_argument("--full-build", action="store_true", help="the whole C. elegans-sized build (README.md:90-91: 16.5 G k-mers = 20 steps, no warm-up); adds build_time_s; the filter is sized with 5 %% head room on N (the README numbers sit exactly at the edge of 8 rounds)")
+    ap.add_argument("--full-build", action="store_true", help="the whole C. elegans-sized build (README.md:90-91: 16.5 G k-mers = 20 steps, no warm-up)")
     ap.add_argument("--host-text", action="store_true", help="hand the FASTQ text over in (pinned) host memory: PCIe-inclusive rate, never the headline value")
     args = ap.parse_args()
     if args.full_build:
         args.steps, args.warmup = 20, 0
     default_workload = (args.reads_per_step == 8_000_000 and args.genome == 119_157_843 and args.qb == 0 and not args.ablate
-                        and args.gpus == 1 and not args.host_text and not args.full_build)
+                        and args.gpus == 1 and not args.host_text)
 
     import torch
     import shk
+    from shk import plan
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,81 +182,85 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     K, L, ERR = 47, 150, 0.00234
-    N_README, n_README = 16506371070, 119157843            # README.md:90-91
     R = args.reads_per_step
-    # README sizing; when the planned run presents more k-mers than the README's N (weak
-    # scaling over several GPUs) the same formulas are applied to the planned total
-    # Weak scaling: with G GPUs the data set is G times larger (G x the genome, G x the distinct true
-    # k-mers, G x the reads per step) and so is the filter, so every GPU keeps a C. elegans-sized shard.
-    N_plan = max(N_README * world, world * (args.steps + args.warmup) * R * (L - K + 1))
-    if args.full_build:
-        N_plan = int(N_plan * 1.05)
-    qb, nd, trigger = sizing(K, n_README * world, N_plan, ERR)
-    if args.qb:
-        qb = args.qb
     rec = 2 * L + NAME_W + 6
     kmers_per_read = L - K + 1
     offs, lens = chunk_table(R, rec)
-    assert len(offs) <= shk.MAX_CHUNKS
+    assert len(offs) * world <= shk.MAX_CHUNKS
+    # The timed region is ONE CLEAN BUILD: `steps` batches into an empty filter (warm-up runs on a scratch
+    # filter of the same geometry). Its command line follows the README recipe (README.md:84-98): -N = the
+    # k-mers the build presents, -n = the genome's k-mers, -e = the generator's error rate; sizing as
+    # src/CQF-deNoise.cpp:96-161; rounds added when the predicted peak load exceeds --max-load (shk/plan.py).
+    # Weak scaling: with G GPUs the data set is G times larger (G x the genome, G x the reads per step) and
+    # so is the filter: every GPU keeps a C. elegans-sized shard.
+    G_total = args.genome * world
+    pl = plan.plan_build(K, G_total, L, ERR, R * kmers_per_read * world / len(offs), len(offs) * args.steps,
+                         world=world, max_load=args.max_load)
+    qb, nd, trigger = pl["qb"], pl["rounds"], pl["trigger"]
+    if args.qb:
+        qb = args.qb
 
-    ctx = shk.Context(qb=qb, k=K, trigger=(trigger if not sharded else (1 << 62)), num_denoise=(nd if not sharded else 0),
-                      max_batch_bytes=(R * (2 * L + NAME_W + 6) + 4096 if args.host_text else 64), max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
-                      max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
-    tot = ctx.totals()
+    def new_ctx():
+        return shk.Context(qb=qb, k=K, trigger=(trigger if not sharded else (1 << 62)), num_denoise=(nd if not sharded else 0),
+                           max_batch_bytes=(R * rec + 4096 if args.host_text else 64),
+                           max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
+                           max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
 
-    genome = torch.randint(0, 4, (args.genome * world,), device=device, dtype=torch.uint8,
+    genome = torch.randint(0, 4, (G_total,), device=device, dtype=torch.uint8,
                            generator=torch.Generator(device=device).manual_seed(2))
-    nsteps = args.steps + args.warmup
     texts = [gen_batch_torch(torch, genome, R, L, ERR, (s * world + rank) * R, 1000 + s * world + rank, device)
-             for s in range(nsteps)]
+             for s in range(args.steps)]
     torch.cuda.synchronize()
     if args.host_text:
         texts = [t.cpu().pin_memory() for t in texts]
 
     hb = qb + 8
     from shk import dist as shkdist
-    sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
-    counted_global = [0]
-    uploaded = {}
-    shard_shift = (qb - int(math.log2(world))) + 8
-    rounds_left = nd
-    counted = 0
-    removed_total = 0
-    rounds_fired = 0
 
-    def step(s):
-        nonlocal rounds_left, counted, removed_total, rounds_fired
-        t = texts[s]
-        if not sharded:
-            if args.host_text:
-                # overlapped ingest: this batch's copy was started before the previous batch was counted
-                if s not in uploaded:
-                    uploaded[s] = ctx.upload_text(t.data_ptr(), t.numel())
-                dptr = uploaded.pop(s)
-                if s + 1 < nsteps:
-                    uploaded[s + 1] = ctx.upload_text(texts[s + 1].data_ptr(), texts[s + 1].numel())
-                st = ctx.count_chunks(dptr, offs, lens, on_device=True, text_bytes=t.numel())
+    class Run:
+        """one filter being built: the context plus the counters of the run"""
+
+        def __init__(self):
+            self.ctx = new_ctx()
+            self.sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
+            self.counted = self.removed = self.rounds = 0
+            self.uploaded = {}
+
+        def step(self, s, nsteps):
+            ctx, t = self.ctx, texts[s]
+            if not sharded:
+                if args.host_text:
+                    # overlapped ingest: this batch's copy was started before the previous batch was counted
+                    if s not in self.uploaded:
+                        self.uploaded[s] = ctx.upload_text(t.data_ptr(), t.numel())
+                    dptr = self.uploaded.pop(s)
+                    if s + 1 < nsteps:
+                        self.uploaded[s + 1] = ctx.upload_text(texts[s + 1].data_ptr(), texts[s + 1].numel())
+                    st = ctx.count_chunks(dptr, offs, lens, on_device=True, text_bytes=t.numel())
+                else:
+                    st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
             else:
-                st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
-            counted += st["kmers"]
-            removed_total += st["removed"]
-            rounds_fired += st["denoise_rounds"]
-            return
-        dp, nw = ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
-        recv = shkdist.route_words(ctx, nw, hb, world, rank, device)
-        torch.cuda.synchronize()
-        ctx.stage_words(recv.data_ptr(), recv.numel())
-        r = shkdist.sharded_count(ctx, sstate, len(offs) * world)
-        counted_global[0] += r["kmers"]
-        removed_total += r["removed"]
-        rounds_fired += r["denoise_rounds"]
+                dp, nw = ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
+                recv = shkdist.route_words(ctx, nw, hb, world, rank, device)
+                torch.cuda.synchronize()
+                ctx.stage_words(recv.data_ptr(), recv.numel())
+                st = shkdist.sharded_count(ctx, self.sstate, len(offs) * world)   # counts are whole-job (all-reduced)
+            self.counted += st["kmers"]
+            self.removed += st["removed"]
+            self.rounds += st["denoise_rounds"]
 
-    for s in range(args.warmup):
-        step(s)
-    counted = 0
-    counted_global[0] = 0
-    removed_total = 0
-    rounds_fired = 0
+    if args.warmup:
+        # untimed passes over the first batches into a scratch filter (same geometry, same schedule): loads the code
+        # objects, sizes the lazily allocated buffers' pools, warms RCCL
+        w = Run()
+        for s in range(args.warmup):
+            w.step(s % args.steps, args.steps)
+        torch.cuda.synchronize()
+        w.ctx.close()
+        del w
+    run = Run()
+    ctx = run.ctx
+    tot = ctx.totals()
     if args.ablate:
         os.environ["SHK_ABLATE"] = str(args.ablate)
     ctx.profile(True)
@@ -310,64 +269,73 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.warmup, nsteps):
-        step(s)
+    for s in range(args.steps):
+        run.step(s, args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
+    end = ctx.totals()
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        counted = counted_global[0]      # already the whole-job count (all-reduced inside sharded_count)
+    counted, removed_total, rounds_fired = run.counted, run.removed, run.rounds
 
     if rank == 0:
-        # dominant kernel by accumulated device time
+        # dominant kernel by accumulated device time (HIP events on the library's stream)
         name, (launches, ms) = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("none", (1, 1.0))
         avg_s = ms / 1e3 / max(launches, 1)
         per_rank_kmers = counted / world
-        units_per_launch = per_rank_kmers / max(launches, 1)
-        achieved = ALGO_BYTES_PER_KMER * units_per_launch / avg_s / 1e9
-        # HBM traffic of the dominant kernel: PMC counters cannot run inside the timed loop; the number comes
-        # from the committed separate --pmc passes over this same default workload (null for any other workload)
-        traffic, traffic_src = None, None
+        # measured HBM traffic: PMC counters cannot run inside the timed loop; the numbers come from the committed
+        # separate --pmc passes over this same default workload (null for any other workload)
+        traffic, traffic_src, step_traffic = None, None, None
         try:
-            pt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pk = {"k_region_merge<spill>": "k_region_merge<3, 24>", "k_region_place": "k_region_place<24>"}.get(name, name)
             if default_workload and pk in pt["kernels"]:
                 traffic = pt["kernels"][pk]["fetch_bytes_per_launch"] + pt["kernels"][pk]["write_bytes_per_launch"]
                 traffic_src = pt["source"]
+            if default_workload:
+                step_traffic = pt.get("bytes_per_step")
         except (OSError, ValueError, KeyError):
             pass
         kern_ms = {k: round(v[1], 3) for k, v in prof.items()}
         kern_n = {k: int(v[0]) for k, v in prof.items()}
         table_bytes = tot.table_bytes
+        # algorithmic bytes of the whole path = 179 B per k-mer presented + 2 x table per deNoise round
         path_bytes = ALGO_BYTES_PER_KMER * per_rank_kmers + rounds_fired * 2 * table_bytes
         out = {
             "metric": "k-mers counted/sec (whole node), CQF build, C.elegans-like k=47",
             "value": counted / dt, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C.elegans-like synthetic reads (G=%d x n_gpus, L=150, e=0.00234), k=47, CQF qb=%d hb=%d "
-                                   "(README.md:98 sizing, N=%d), %d reads/step/GPU, 8 MiB chunks, deNoise rounds=%d trigger=%d"
-                                   % (args.genome, qb, hb, N_plan, R, nd, trigger),
+            "build_time_s": dt, "build_kmers": counted, "build_rounds": rounds_fired,
+            "config": {"workload": "clean CQF build from an empty filter: C.elegans-like synthetic reads (genome %d x n_gpus, L=150, e=0.00234), "
+                                   "CQF-deNoise -k 47 -N %d -n %d -e 0.00234 -> qb=%d hb=%d rounds=%d trigger=%d (src/CQF-deNoise.cpp:96-161); "
+                                   "run with rounds=%d trigger=%d (rounds added until the predicted peak load %.3f <= %.2f, shk/plan.py); "
+                                   "%d steps x %d reads/step/GPU, 8 MiB chunks; warm-up on a scratch filter"
+                                   % (args.genome, pl["N"], pl["n"], pl["qb"], pl["qb"] + 8, pl["formula_rounds"], pl["formula_trigger"],
+                                      nd, trigger, pl["predicted_peak_load"], args.max_load, args.steps, R),
                        "kmers_per_step_per_gpu": R * kmers_per_read, "denoise_rounds_fired": rounds_fired,
-                       "removed": removed_total, "parallelism": "quotient-range shards x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "launches": launches, "avg_launch_ms": avg_s * 1e3,
-                         "algorithmic_bytes_per_kmer": ALGO_BYTES_PER_KMER},
-            "roofline_path": {"achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                              "frac": path_bytes / dt / HBM_PEAK,
-                              "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)"},
+                       "removed": removed_total, "parallelism": "quotient-range shards x%d" % world,
+                       "final_nelts": (run.sstate.nelts if sharded else end.nelts), "final_ndistinct": (run.sstate.ndistinct if sharded else end.ndistinct),
+                       "final_free_pointer_over_xnslots": end.free_pointer / end.xnslots},
+            # the path-level figure; `traffic` = measured HBM bytes per step (separate --pmc passes)
+            "roofline": {"bound": "hbm", "scope": "whole insert path: hash + partition + rebuild + deNoise rounds",
+                         "achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": path_bytes / dt / HBM_PEAK, "traffic": step_traffic, "traffic_unit": "bytes/step (measured, all kernels)",
+                         "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)",
+                         "algorithmic_bytes_per_kmer": ALGO_BYTES_PER_KMER, "table_bytes": table_bytes},
+            # the kernel with the most device time, on its MEASURED bytes (no algorithmic figure applies to one stage)
+            "dominant_kernel": {"kernel": name, "launches": launches, "avg_launch_ms": avg_s * 1e3, "share_of_step": ms / 1e3 / dt,
+                                "traffic": traffic, "traffic_unit": "bytes/launch (measured)", "traffic_source": traffic_src,
+                                "achieved_real_GBps": (traffic / avg_s / 1e9) if traffic else None},
             "kernel_ms": kern_ms, "kernel_launches": kern_n,
-            **({"build_time_s": dt, "build_kmers": counted, "build_rounds": rounds_fired} if args.full_build else {}),
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-            text_cpu = texts[args.warmup].cpu().numpy().tobytes()
+            text_cpu = texts[0].cpu().numpy().tobytes()
             out["cpu_baseline"] = cpu_baseline(torch, text_cpu, offs, lens, K, qb)
         print(json.dumps(out))
     ctx.close()
