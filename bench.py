@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: SHK_ABLATE bits applied to the timed steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace", action="store_true", help="diagnostics: print the filter's counters after every step (adds a sync per step)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/all-to-all code path even with one rank")
     ap.add_argument("--full-build", action="store_true", help="the whole C. elegans-sized build (README.md:90-91: 16.5 G k-mers = 20 steps, no warm-up)")
     ap.add_argument("--host-text", action="store_true", help="hand the FASTQ text over in (pinned) host memory: PCIe-inclusive rate, never the headline value")
@@ -248,6 +249,10 @@ def main():
             self.counted += st["kmers"]
             self.removed += st["removed"]
             self.rounds += st["denoise_rounds"]
+            if args.trace and rank == 0:
+                tt = ctx.totals()
+                print("step %d: nelts %d ndistinct %d rounds %d free_pointer %d / %d" % (s, tt.nelts, tt.ndistinct, self.rounds, tt.free_pointer, tt.xnslots),
+                      file=sys.stderr, flush=True)
 
     if args.warmup:
         # untimed passes over the first batches into a scratch filter (same geometry, same schedule): loads the code

@@ -1,10 +1,11 @@
-// Host-side FASTQ chunker: same interface and behaviour as the reference's seqFile_batch /
-// fastq_read_parts (cqf/CQF_mt.h:334-412, 561-585, 735-816, 933-957), written against
-// stdio + zlib only (no boost lock-free queue: one host thread feeds the GPU).
+// Host-side FASTQ chunker. Hands out the same parts, in the same order, as the reference's
+// seqFile_batch / fastq_read_parts (cqf/CQF_mt.h:334-412, 561-585, 735-816, 933-957) -- the parts are
+// the points at which the deNoise trigger is tested, so their sizes are part of the result -- but is
+// organised differently: a ByteSource per compression format, a growing carry buffer per file and a
+// record-boundary search over a read-only text view. One host thread feeds the GPU (no lock-free queue).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
-#include <zlib.h>
 #include <deque>
 #include <memory>
 #include <string>
@@ -23,15 +24,19 @@ struct chunk {                              // cqf/chunk.h:23-41 (the part of it
   void set(char *r, uint64_t s) { reads = r; size = s; }
 };
 
-struct file_pointer {                       // cqf/CQF_mt.h:324-331
-  FILE *in = nullptr;
-  gzFile in_gzip = nullptr;
-  void *in_bzip2 = nullptr;                 // BZFILE* (libbz2 is bound at run time, see fastq_chunker.cpp)
-  int bzerror = 0;
-  std::vector<char> part_buffer;            // carry-over between parts
-  FILE_MODE fmode = TEXT;
-  uint64_t part_filled = 0;
+// sequential byte stream over a plain, gzip or bzip2 file
+class ByteSource {
+ public:
+  virtual ~ByteSource() {}
+  virtual uint64_t read(char *dst, uint64_t n) = 0;   // bytes delivered (short only at the end of the stream)
+  virtual bool at_end() const = 0;                    // the format's own end-of-stream flag (raised by a short read)
+  static std::unique_ptr<ByteSource> open(const std::string &path, FILE_MODE mode);   // null when unreadable
 };
+
+// Where to cut a buffer of FASTQ text so that the cut falls on a record start: the first of the four line starts
+// behind position `n - overhead/2` that begins with '@' while the line two further on begins with '+' and is either
+// bare or repeats the header (cqf/CQF_mt.h:781-808). 0 when the tail holds no such line (the whole buffer is carried).
+uint64_t fastq_record_cut(const char *text, uint64_t n, uint32_t overhead);
 
 class seqFile_batch {
  public:
@@ -47,9 +52,12 @@ class seqFile_batch {
   bool bad() const { return bad_; }         // "Error: Wrong input file!" (CQF_mt.h:764-768)
 
  private:
-  bool read_part(file_pointer *fp, chunk &out);
-  bool is_eof(file_pointer *fp) const;
-  std::deque<std::unique_ptr<file_pointer>> files_;
+  struct OpenFile {
+    std::unique_ptr<ByteSource> src;
+    std::vector<char> carry;                // text behind the last cut, prepended to the next part
+  };
+  bool next_part(OpenFile &f, chunk &out);
+  std::deque<std::unique_ptr<OpenFile>> files_;
   uint64_t part_size_;
   uint32_t overhead_;
   bool bad_ = false;

@@ -25,6 +25,18 @@ int shkh_stitch(const uint8_t *const *shards, const uint64_t *shard_blocks, uint
                 uint64_t out_bytes) {
   return shk::stitch_shards(shards, shard_blocks, nshards, qb, out, out_bytes);
 }
+// alpha = -1: the true:false ratio comes from the error profile file
+void shkh_size_filter_profile(int K, uint64_t n_true, uint64_t N_total, const char *profile, int num_denoise, double fr, uint64_t *out) {
+  shk::Sizing s = shk::size_filter(K, n_true, N_total, -1, profile, num_denoise, fr);
+  out[0] = s.qb; out[1] = s.hb; out[2] = (uint64_t)s.num_deNoise; out[3] = s.n_distinct_elts_for_DeNoise;
+  out[4] = s.num_true_kmers; out[5] = s.num_false_kmers; out[6] = (uint64_t)s.lower_bound; out[7] = (uint64_t)s.upper_bound;
+}
+double shkh_true_to_false_ratio(const double *rates, uint64_t n, uint64_t K) {
+  return shk::ErrorProfile(std::vector<double>(rates, rates + n)).true_to_false_ratio(K);
+}
+int shkh_rounds_for_loss_rate(double mean, double fr) { return shk::rounds_for_loss_rate(mean, fr); }
+// the cut fastq_read_parts would make in this buffer (0 = none found)
+uint64_t shkh_record_cut(const char *text, uint64_t n, uint32_t overhead) { return shk::fastq_record_cut(text, n, overhead); }
 void shkh_size_filter(int K, uint64_t n_true, uint64_t N_total, double alpha, int num_denoise, double fr, uint64_t *out) {
   shk::Sizing s = shk::size_filter(K, n_true, N_total, alpha, "", num_denoise, fr);
   out[0] = s.qb; out[1] = s.hb; out[2] = (uint64_t)s.num_deNoise; out[3] = s.n_distinct_elts_for_DeNoise;

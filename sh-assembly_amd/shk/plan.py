@@ -106,6 +106,34 @@ def _entry_slots(count):
     return 1.0 + nd + top / 256.0
 
 
+_SLOT_GRID = {}
+
+
+def _mean_entry_slots(mean):
+    """_mean_entry_slots_exact on a grid of integer means, linearly interpolated (the simulation asks thousands of times)"""
+    a = int(mean)
+    for m in (a, a + 1):
+        if m not in _SLOT_GRID:
+            _SLOT_GRID[m] = _mean_entry_slots_exact(float(m))
+    return _SLOT_GRID[a] + (mean - a) * (_SLOT_GRID[a + 1] - _SLOT_GRID[a])
+
+
+def _mean_entry_slots_exact(mean):
+    """E[_entry_slots(X)] for X ~ Poisson(mean) given X >= 2: the counts of a class spread around their mean, and
+    the encoding grows by a slot at 129, 16385, ... (a class whose mean count is 125 has 40 % of its entries beyond 128)"""
+    if mean <= 2.0:
+        return _entry_slots(2)
+    sd = math.sqrt(mean)
+    lo, hi = max(2, int(mean - 6 * sd)), int(mean + 6 * sd) + 2
+    logm = math.log(mean)
+    num = den = 0.0
+    for x in range(lo, hi + 1):
+        w = math.exp(x * logm - mean - math.lgamma(x + 1.0))
+        num += w * _entry_slots(x)
+        den += w
+    return num / den if den > 0 else _entry_slots(mean)
+
+
 class _Class:
     """a population of `size` possible k-mers that each arrive at the same Poisson rate:
     p1 = fraction sitting in the table with count 1, p2 = with count >= 2 (survives deNoise)"""
@@ -135,7 +163,7 @@ class _Class:
 
     def slots(self):
         mean2 = self.mass2 / self.p2 if self.p2 > 0 else 2.0
-        return self.size * (self.p1 + self.p2 * _entry_slots(mean2))
+        return self.size * (self.p1 + self.p2 * _mean_entry_slots(mean2))
 
 
 def predict_build(K, G, L, err, kmers_per_chunk, nchunks, trigger, rounds, trace_every=0):

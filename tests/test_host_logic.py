@@ -112,3 +112,108 @@ def test_cpp_sizing_matches_oracle():
         out = (C.c_uint64 * 8)()
         L.shkh_size_filter(K, n, N, e, -1, 0.0, out)
         assert (out[0], out[2], out[3]) == b.sizing(K, n, N, e)
+
+
+def _sizing_api():
+    import ctypes as C
+    L = _hostlib()
+    L.shkh_true_to_false_ratio.restype = C.c_double
+    L.shkh_true_to_false_ratio.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint64]
+    L.shkh_rounds_for_loss_rate.argtypes = [C.c_double, C.c_double]
+    L.shkh_size_filter_profile.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_double, C.POINTER(C.c_uint64)]
+    L.shkh_record_cut.restype = C.c_uint64
+    L.shkh_record_cut.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32]
+    return L
+
+
+def test_error_profile_ratio_closed_forms():
+    """true2falseKmer_DP (cqf/true2falseKmer_DP.cpp:12-50) = E[error-free windows] / E[erroneous windows]:
+    a constant profile e gives (1-e)^K / (1 - (1-e)^K) whatever the read length; any profile equals the
+    direct sum over windows of prod(1 - e_i); a hand-computed two-value profile"""
+    import ctypes as C
+    import math
+    import random
+    L = _sizing_api()
+
+    def ratio(rates, K):
+        return L.shkh_true_to_false_ratio((C.c_double * len(rates))(*rates), len(rates), K)
+    for e, K, ln in [(0.01, 28, 150), (0.00234, 47, 150), (0.005, 31, 100), (0.2, 5, 5), (0.0, 31, 100)]:
+        p = (1 - e) ** K
+        want = p / (1 - p) if e else math.inf
+        got = ratio([e] * ln, K)
+        assert got == want or abs(got - want) <= 1e-9 * want
+    # two values, K = 2, read of 3 bases: windows (a,b) and (b,a')
+    a, b = 0.1, 0.3
+    clean = (1 - a) * (1 - b) + (1 - b) * (1 - a)
+    assert abs(ratio([a, b, a], 2) - clean / (2 - clean)) < 1e-15
+    rng = random.Random(5)
+    for K, ln in [(31, 100), (47, 150), (3, 40), (1, 7)]:
+        rates = [rng.random() * 0.05 for _ in range(ln)]
+        clean = sum(math.prod(1 - r for r in rates[s:s + K]) for s in range(ln - K + 1))
+        assert abs(ratio(rates, K) - clean / (ln - K + 1 - clean)) < 1e-9 * (clean / (ln - K + 1 - clean))
+    # the oracle's restatement (which follows the reference's loops literally) gives the same double
+    O = cqflibs.oracle()
+    O.L.orc_true2false_dp.restype = C.c_double
+    O.L.orc_true2false_dp.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_size_t]
+    rates = [0.001 + 0.019 * i / 149 for i in range(150)]       # BASELINE config 5: linear 0.001 -> 0.02
+    arr = (C.c_double * 150)(*rates)
+    assert ratio(rates, 31) == O.L.orc_true2false_dp(arr, 150, 31)
+
+
+def test_rounds_match_scipy_poisson():
+    """rounds_for_loss_rate (mean_CDF2deNoise, cqf/CQF_mt.h:94-133; boost's Poisson CDF replaced by a summed pmf)
+    against the same search on scipy's Poisson CDF: every BASELINE config and a sweep -- identical rounds"""
+    from shk import plan
+    L = _sizing_api()
+    cases = [(124.0, 1 / 119157843), (26.0, 1 / 2.9e9), (26.0, 1e-6), (88.0, 1 / 2.9e9), (22.0, 1 / 4.6e6), (139.0, 1 / 119157843)]
+    for m in range(1, 400, 7):
+        for fr in (1e-3, 1e-6, 1e-9, 1e-12):
+            cases.append((float(m), fr))
+    for mean, fr in cases:
+        assert L.shkh_rounds_for_loss_rate(mean, fr) == plan.mean_cdf2denoise(mean, fr), (mean, fr)
+
+
+def test_sizing_with_error_profile(tmp_path):
+    """--errorProfile sizing (src/CQF-deNoise.cpp:103-106): C++ host == python restatement == oracle, for the
+    BASELINE config 5 shape (human 100x, k = 31, linear profile 0.001 -> 0.02)"""
+    import ctypes as C
+    from shk import plan
+    L = _sizing_api()
+    rates = [0.001 + 0.019 * i / 149 for i in range(150)]
+    pf = tmp_path / "profile.txt"
+    pf.write_text("".join("%.17g\n" % r for r in rates))
+    K, n, N = 31, 2_900_000_000, 300_000_000_000
+    out = (C.c_uint64 * 8)()
+    L.shkh_size_filter_profile(K, n, N, str(pf).encode(), -1, 0.0, out)
+    r = L.shkh_true_to_false_ratio((C.c_double * 150)(*rates), 150, K)
+    assert (out[0], out[2], out[3]) == plan.sizing(K, n, N, -1, ratio=r)
+    assert out[4] == int(N * r / (1 + r)) and out[4] + out[5] == N
+    assert out[0] in (33, 34, 35)
+
+
+def test_record_cut_and_malformed_input(tmp_path):
+    """fastq_record_cut: the cut is the first '@' line among four consecutive line starts behind n - overhead/2 whose
+    line + 2 starts with '+' (bare or repeating the header); input without record structure makes the chunker
+    stop with 'Wrong input file' instead of growing its carry without bound (the reference reads a
+    whole part behind a carry that may already fill its buffer, CQF_mt.h:745-768)"""
+    import ctypes as C
+    L = _sizing_api()
+    rec = b"@r1\nACGT\n+\nIIII\n"
+    buf = rec * 40
+    cut = L.shkh_record_cut(buf, len(buf), 200)
+    assert cut and cut % len(rec) == 0 and cut >= len(buf) - 100
+    rec2 = b"@name\nAC\n+name\nII\n"                      # '+' line repeats the header
+    buf2 = rec2 * 40
+    cut2 = L.shkh_record_cut(buf2, len(buf2), 200)
+    assert cut2 and cut2 % len(rec2) == 0
+    q = b"@r\nAC\n+\n@@\n" * 40                           # quality lines that start with '@' are not record starts
+    cq = L.shkh_record_cut(q, len(q), 200)
+    assert cq and cq % 11 == 0
+    assert L.shkh_record_cut(b"A" * 5000, 5000, 200) == 0      # no line structure at all
+    assert L.shkh_record_cut(b"ACGT\n" * 1000, 5000, 200) == 0  # lines, but no record
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"ACGTACGTAC\n" * 20000)                 # 220 kB without any '@'
+    arr = (C.c_char_p * 1)(str(bad).encode())
+    out = (C.c_uint64 * 64)()
+    n = L.shkh_chunk_sizes(arr, 1, 0, 20000, 4095, out, 64)
+    assert n <= 1 and (n == 0 or out[0] == 0)                # at most the first (empty) part, then the error
