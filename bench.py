@@ -326,7 +326,7 @@ def main():
                        "kmers_per_step_per_gpu": R * kmers_per_read, "denoise_rounds_fired": rounds_fired,
                        "removed": removed_total, "parallelism": "quotient-range shards x%d" % world,
                        "final_nelts": (run.sstate.nelts if sharded else end.nelts), "final_ndistinct": (run.sstate.ndistinct if sharded else end.ndistinct),
-                       "final_free_pointer_over_xnslots": end.free_pointer / end.xnslots},
+                       "predicted_peak_load": pl["predicted_peak_load"]},
             # the path-level figure; `traffic` = measured HBM bytes per step (separate --pmc passes)
             "roofline": {"bound": "hbm", "scope": "whole insert path: hash + partition + rebuild + deNoise rounds",
                          "achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
