@@ -22,12 +22,20 @@
  *   shk_select_seeds      processDataChunk's seed rule                     src/contig_assembly.cpp:1856-1876
  *   shk_find_unitigs      find_unitigs: seeds + work queue of branch
  *                         neighbours + duplicate removal + writer (set-level) src/contig_assembly.cpp:3122-3160, 935-954, 606-626
+ *   shk_insert_counted    qf_insert_advance(count > 1) -> insert_advance    cqf/gqf.c:2024-2136 (local-QF flush, CQF_mt.h:588-607)
+ *   shk_dump              qf_iterator / qfi_get / qfi_next / qfi_end        cqf/gqf.c:2474-2601
+ *   shk_merge             qf_merge                                          cqf/gqf.c:2614-2655
+ *   shk_multi_merge       qf_multi_merge                                    cqf/gqf.c:2660-2704
+ *   shk_import_shards     (no counterpart: the reference is one process) quotient-range shards -> the single table
  *   shk_stats             runtime->nelts / ndistinct_elts / num_deNoise    cqf/CQF_mt.h:277-288
  *   shk_destroy           CQF_mt::~CQF_mt -> qf_destroy                    cqf/CQF_mt.h:547-557; gqf.c:2306
  *
  * Errors: every call returns 0 or a negative SHK_ERR_* code; the library never exits
  * the process (the reference perror()+exit()s, gqf.c:2244-2247) and, unlike the
- * reference, detects a full table (SHK_ERR_TABLE_FULL) before anything is written.
+ * reference, detects a full table (SHK_ERR_TABLE_FULL) before the pass that would overflow writes anything.
+ * Granularity of an error inside shk_count_chunks / shk_count_words: the call works through its chunks in ranges (a
+ * range ends where a deNoise round fires); ranges and rounds completed before the failing range stay committed and
+ * `stats` reports them (stats->chunks = chunks consumed), the failing range leaves the table as it was.
  * A context is not re-entrant; use one context per thread / per GPU.
  */
 #ifndef SHK_H
@@ -45,7 +53,7 @@ enum {
   SHK_ERR_ARG = -1,          /* bad argument / unsupported geometry */
   SHK_ERR_HIP = -2,          /* a HIP runtime call failed (no GPU, out of memory, ...) */
   SHK_ERR_TABLE_FULL = -3,   /* runs would pass xnslots */
-  SHK_ERR_REGION = -4,       /* one 2048-quotient region exceeded the kernel's LDS image or hash */
+  SHK_ERR_REGION = -4,       /* one 256-quotient region exceeded the kernel's LDS image or hash */
   SHK_ERR_CORRUPT = -5,      /* table metadata inconsistent / key outside this context's range */
   SHK_ERR_FASTQ = -6,        /* malformed input: read longer than 65535, too many reads */
   SHK_ERR_BATCH = -7,        /* batch larger than the capacities given at create time */
@@ -170,6 +178,31 @@ int shk_stage_chunk_hist(shk_ctx *ctx, uint64_t *out, uint32_t n);
 
 /* One deNoise round now (the reference's --endDeNoise round; does not use up num_denoise). */
 int shk_denoise(shk_ctx *ctx, uint64_t *removed);
+
+/* ---- filter-to-filter utilities
+ * shk_insert_counted: add `counts[i]` occurrences of keys[i] (keys < 2^hb inside this context's quotient range), the
+ *   batched form of qf_insert_advance(qf, key, 0, count, ...). No deNoise round fires inside (the reference tests its
+ *   trigger after a chunk of reads only). stats->kmers = occurrences added, stats->new_distinct = keys that were new.
+ * shk_dump: (key, count) of every entry, in the order qf_iterator/qfi_next visit them (ascending key); *n_out = number
+ *   of entries; at most `cap` pairs are written; keys == NULL only counts. key = (quotient << 8) | remainder (qfi_get).
+ *   The reference's qfi_next ends the iteration when it steps inside a run onto a slot behind nslots (gqf.c:2537-2539),
+ *   so entries in the overflow tail that do not open their run, and all behind them, are invisible to its iterator and
+ *   to qf_merge: ref_iterator_end != 0 makes *n_out that (smaller) number; 0 = every entry.
+ * shk_merge: dst := dst + src -- what qf_merge(a, b, c) leaves in c for a = dst, b = src: the canonical table of the
+ *   summed multiset (same geometry, same device). stats->kmers = occurrences added, new_distinct = keys new to dst.
+ * shk_multi_merge: the same for several sources (qf_multi_merge).
+ * shk_import_shards: replace the table (whole-filter context, num_shards <= 1) by the union of `nshards` quotient-range
+ *   shards, each in the layout shk_export_blocks gives for a context with num_shards = nshards (its nslots / nshards
+ *   quotients plus its own overflow tail). Device tables need 16 readable bytes behind them. nelts / ndistinct:
+ *   the runtime counters for the header (0 = take the sums found in the shards). */
+int shk_insert_counted(shk_ctx *ctx, const uint64_t *keys, const uint64_t *counts, uint64_t n, int on_device,
+                       shk_batch_stats *stats);
+int shk_dump(shk_ctx *ctx, uint64_t *keys, uint64_t *counts, uint64_t cap, int on_device, int ref_iterator_end,
+             uint64_t *n_out);
+int shk_merge(shk_ctx *dst, shk_ctx *src, shk_batch_stats *stats);
+int shk_multi_merge(shk_ctx *dst, shk_ctx *const *srcs, uint32_t n, shk_batch_stats *stats);
+int shk_import_shards(shk_ctx *ctx, const void *const *shard_blocks, const uint64_t *shard_bytes, uint32_t nshards,
+                      int on_device, uint64_t nelts, uint64_t ndistinct);
 
 int shk_stats(shk_ctx *ctx, shk_totals *out);
 /* 128-byte quotient_filter_metadata image (gqf.h:62-77) for this context */

@@ -112,6 +112,28 @@ uint64_t ref_qf_dump(RefQF *h, uint64_t *keys, uint64_t *counts, uint64_t cap) {
   return n;
 }
 
+// the reference's own merges (gqf.c:2614-2655, 2660-2704): c := a + b, r := sum of arr[] (inputs must be non-empty:
+// qf_merge reads keya/keyb of an empty iterator uninitialised). The runtime counters of the result are what a dump
+// of it gives (gqf.c maintains none: every modify_metadata call is commented out).
+static void ref_recount(RefQF *h) {
+  QFi it; uint64_t n = 0, tot = 0;
+  if (qf_iterator(&h->qf, &it, 0)) {
+    do {
+      uint64_t k = 0, v = 0, c = 0;
+      if (qfi_get(&it, &k, &v, &c)) break;
+      n++; tot += c;
+    } while (!qfi_next(&it));
+  }
+  h->ndistinct = n; h->nelts = tot;
+}
+void ref_qf_merge(RefQF *a, RefQF *b, RefQF *c) { qf_merge(&a->qf, &b->qf, &c->qf); ref_recount(c); }
+void ref_qf_multi_merge(RefQF **arr, int n, RefQF *r) {
+  std::vector<QF *> q(n);
+  for (int i = 0; i < n; i++) q[i] = &arr[i]->qf;
+  qf_multi_merge(q.data(), n, &r->qf);
+  ref_recount(r);
+}
+
 // encode_counter (gqf.c:1225-1255): returns the number of slots, written to out[]
 int ref_encode_counter(RefQF *h, uint64_t remainder, uint64_t counter, uint64_t *out) {
   uint64_t buf[67];

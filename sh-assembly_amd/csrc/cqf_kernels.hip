@@ -55,6 +55,8 @@ struct ShkMergeArgs {
   unsigned long long *n_over;
   const uint32_t *list;           // MODE 1 only: regions to rebuild (null = all, region = blockIdx.x)
   uint16_t *newchunks;            // [nregions * SHK_HCAP] first chunk of every NEW key of the region (null = off; needs want_hist)
+  int counted;                    // 1: the records' chunk field holds (multiplicity - 1) of a counted insert (insert_advance with
+                                  // count > 1, gqf.c:2024-2136); every record takes part, no chunk statistics
 };
 
 __device__ __forceinline__ unsigned shk_img_slot_off(unsigned p) {
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         const uint32_t i = i0 + (uint32_t)u * ngrp + tid;
         wv[u] = i < nw ? wp[i] : ~0u;
       }
-      uint32_t h[4], want[4], chk[4];
+      uint32_t h[4], want[4], chk[4], wgt[4];
       bool pend[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -309,13 +311,14 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         const bool in = i0 + (uint32_t)u * ngrp + tid < nw;
         const uint32_t chunk = w & (SHK_MAX_CHUNKS - 1);
         const uint32_t tag = (w >> SHK_CHUNK_BITS) & 0xFFFFu;
-        const bool inr = in && chunk >= A.chunk_lo && chunk <= A.chunk_hi;
+        const bool inr = in && (A.counted || (chunk >= A.chunk_lo && chunk <= A.chunk_hi));
         corrupt |= inr && (tag >> 8) >= nq;
         pend[u] = inr && (tag >> 8) < nq;
         want[u] = tag << SHK_CHUNK_BITS;
         chk[u] = chunk;
+        wgt[u] = A.counted ? chunk + 1u : 1u;
         h[u] = (__umul24(tag, 40503u) & 0xFFFFu) >> (16 - SHK_HCAP_LOG2);   // 16-bit multiplicative hash, full-rate multiply
-        my_added += pend[u] ? 1u : 0u;
+        my_added += pend[u] ? wgt[u] : 0u;
       }
       if (A.ablate & 256) continue;   // diagnostics: loads + setup only
       uint32_t guard = 0;
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
           }
           if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
-          atomicAdd(&hcnt[h[u]], match ? 1u : 0u);
+          atomicAdd(&hcnt[h[u]], match ? wgt[u] : 0u);
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }

@@ -18,6 +18,7 @@
 #include "kmer_kernels.hip"
 #include "partition_kernels.hip"
 #include "cqf_kernels.hip"
+#include "merge2_kernels.hip"
 #include "walk_kernels.hip"
 
 #define SHK_SLACK 256  // bytes of slack behind buffers read with wide loads
@@ -97,6 +98,7 @@ struct shk_ctx {
   uint32_t last_err_bits;
   double new_frac;              // new distinct keys per presented k-mer in the last committed range (predicts crossings)
   int staged;                   // which d_words[] holds the partitioned words of shk_stage_words
+  int counted;                  // 1 while shk_insert_counted runs: the words' chunk field is a multiplicity
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libshk: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return SHK_ERR_HIP; } } while (0)
@@ -143,7 +145,7 @@ extern "C" const char *shk_strerror(int code) {
     case SHK_ERR_ARG: return "bad argument or unsupported geometry";
     case SHK_ERR_HIP: return "HIP runtime error (is a GPU present?)";
     case SHK_ERR_TABLE_FULL: return "counting quotient filter is full";
-    case SHK_ERR_REGION: return "a 2048-quotient region exceeds the kernel's on-chip image";
+    case SHK_ERR_REGION: return "a 256-quotient region exceeds the kernel's on-chip image or hash";
     case SHK_ERR_CORRUPT: return "table metadata inconsistent or key outside this context's range";
     case SHK_ERR_FASTQ: return "malformed FASTQ input";
     case SHK_ERR_BATCH: return "batch exceeds the capacities given to shk_create";
@@ -434,6 +436,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->dbg = getenv("SHK_STAMPS") ? (unsigned long long *)(c->d_scalars + 16) : nullptr;
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
   A->newchunks = nullptr;
+  A->counted = c->counted;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -1144,6 +1147,267 @@ extern "C" int shk_lookup(shk_ctx *c, const uint64_t *keys, uint64_t n, int on_d
     hipFree(dk); hipFree(dc); hipFree(dt);
   }
   return finish(c, 0);
+}
+
+// ------------------------------------------------------------------ counted inserts, iterator dump, merge, stitch
+// (insert_advance with count > 1 gqf.c:2024-2136; qf_iterator/qfi_* :2474-2601; qf_merge/qf_multi_merge :2614-2704)
+
+// rebuild with the words of a counted insert; nothing is committed unless the pass is clean
+static int merge_plain(shk_ctx *c, const uint64_t *words, MergeOut *o) {
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = merge_summary(c, words, 0, SHK_MAX_CHUNKS - 1, 0, 0, 0, o, 0, 1);
+    if (rc) return rc;
+    if (!c->big_image && (o->err & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) && !(o->err & SHK_E_TABLE_FULL)) { c->big_image = 1; continue; }
+    break;
+  }
+  if (o->err) return SHK_OK;   // the caller looks at o->err
+  return merge_write(c, words, 0, SHK_MAX_CHUNKS - 1, 0);
+}
+
+extern "C" int shk_insert_counted(shk_ctx *c, const uint64_t *keys, const uint64_t *counts, uint64_t n, int on_device,
+                                  shk_batch_stats *stats) {
+  if (!c || (n && (!keys || !counts))) return SHK_ERR_ARG;
+  shk_batch_stats st;
+  memset(&st, 0, sizeof(st));
+  if (stats) *stats = st;
+  if (n == 0) return SHK_OK;
+  HIPCHK(hipSetDevice(c->dev));
+  uint64_t *dk = nullptr, *dc = nullptr, *doff = nullptr;
+  uint32_t *dnw = nullptr;
+  int rc = SHK_OK;
+  struct Free { uint64_t *&a, *&b, *&o; uint32_t *&w; bool own; ~Free() { if (own) { hipFree(a); hipFree(b); } hipFree(o); hipFree(w); } } fr{dk, dc, doff, dnw, !on_device};
+  if (on_device) { dk = (uint64_t *)keys; dc = (uint64_t *)counts; }
+  else {
+    if (dmalloc(&dk, n) || dmalloc(&dc, n)) return SHK_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dc, counts, n * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  // pairs are inserted slice by slice (bounded by the key-word capacity; halved when one region would receive more
+  // distinct new keys than its LDS hash holds); occurrences beyond `take` of one key go into further passes
+  const uint64_t take = 1ULL << 22;
+  const uint64_t key_lo = c->q_lo << 8, key_hi = (c->q_lo + c->nslots) << 8;
+  uint64_t slice = n;
+  { const uint64_t cap = c->cfg.max_batch_keys / 2 > 0 ? c->cfg.max_batch_keys / 2 : 1; if (slice > cap) slice = cap; }
+  if (dmalloc(&doff, slice + 2) || dmalloc(&dnw, slice + 2)) return SHK_ERR_HIP;
+  c->counted = 1;
+  uint64_t done = 0;
+  while (done < n && !rc) {
+    const uint64_t m = n - done < slice ? n - done : slice;
+    uint64_t skip = 0, maxc = 0;
+    bool halve = false;
+    do {
+      HIPCHK(hipMemsetAsync(c->d_scalars + 4, 0, 8, c->stream));
+      const uint32_t nb = (uint32_t)((m + 255) / 256);
+      { ProfScope ps(c, KP_MISC);
+        hipLaunchKernelGGL(k_expand_counted<0>, dim3(nb), dim3(256), 0, c->stream, dk + done, dc + done, m, skip, take, c->cfg.hb, dnw,
+                           (const uint64_t *)nullptr, (uint64_t *)nullptr, c->d_err, key_lo, key_hi, (unsigned long long *)(c->d_scalars + 4)); }
+      if (run_scan<uint32_t>(c, dnw, m, nullptr, doff)) { rc = SHK_ERR_HIP; break; }
+      HIPCHK(hipMemcpyAsync(c->h_pinned + 45, doff + m, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(c->h_pinned + 46, c->d_scalars + 4, 8, hipMemcpyDeviceToHost, c->stream));
+      uint32_t bits = 0;
+      if (fetch_err(c, &bits)) { rc = SHK_ERR_HIP; break; }
+      if (bits) { rc = map_err_bits(bits); break; }
+      const uint64_t nwords = c->h_pinned[45];
+      maxc = c->h_pinned[46];
+      if (nwords > c->cfg.max_batch_keys) { halve = true; break; }
+      if (nwords) {
+        { ProfScope ps(c, KP_MISC);
+          hipLaunchKernelGGL(k_expand_counted<1>, dim3(nb), dim3(256), 0, c->stream, dk + done, dc + done, m, skip, take, c->cfg.hb, dnw,
+                             doff, c->d_words[0], c->d_err, key_lo, key_hi, (unsigned long long *)nullptr); }
+        c->h_pinned[43] = nwords;
+        HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
+        int dst = 0;
+        rc = partition_stage(c, 0, nwords, &dst);
+        if (rc) break;
+        MergeOut o;
+        rc = merge_plain(c, c->d_words[dst], &o);
+        if (rc) break;
+        if (o.err & SHK_E_HASH_FULL) { if (skip) { rc = SHK_ERR_REGION; break; } halve = true; break; }
+        if (o.err) { rc = map_err_bits(o.err); break; }
+        c->nelts += o.added; c->ndistinct += o.newd;
+        st.kmers += o.added; st.new_distinct += o.newd;
+      }
+      skip += take;
+    } while (maxc > skip);
+    if (rc) break;
+    if (halve) {
+      if (slice == 1) { rc = SHK_ERR_REGION; break; }
+      slice = (slice + 1) / 2;
+      continue;
+    }
+    done += m;
+  }
+  c->counted = 0;
+  if (stats) *stats = st;
+  return finish(c, rc);
+}
+
+// (key, count) of every entry in the order of the reference's iterator. keys == NULL: only the number of entries.
+// ref_iterator_end != 0: *n_out is where the reference's own iteration would END (see k_region_dump).
+extern "C" int shk_dump(shk_ctx *c, uint64_t *keys, uint64_t *counts, uint64_t cap, int on_device, int ref_iterator_end,
+                        uint64_t *n_out) {
+  if (!c || !n_out || (keys && !counts)) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  ShkMergeArgs A;
+  fill_args(c, &A, nullptr, 0, 0, 0, 0, 0);
+  uint32_t *nper = c->d_over_list;                       // scratch of the spill scheme: [nregions + 1]
+  uint64_t *offs = (uint64_t *)c->d_lb_agg;              // [nregions + 2]
+  unsigned long long *stop = (unsigned long long *)(c->d_scalars + 5);
+  const uint64_t *no_offs = nullptr;
+  uint64_t *no_out = nullptr;
+  c->spill_valid = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    { ProfScope ps(c, KP_MISC);
+      if (c->big_image) hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr);
+      else hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr); }
+    uint32_t bits = 0;
+    if (fetch_err(c, &bits)) return SHK_ERR_HIP;
+    if ((bits & SHK_E_OLD_EXTENT) && !c->big_image) { c->big_image = 1; c->last_err_bits = 0; continue; }
+    if (bits) { prof_collect(c); return map_err_bits(bits); }
+    break;
+  }
+  if (run_scan<uint32_t>(c, nper, c->nregions, nullptr, offs)) return SHK_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 45, offs + c->nregions, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint64_t total = c->h_pinned[45];
+  *n_out = total;
+  if (!keys && !ref_iterator_end) return finish(c, 0);
+  const uint64_t m = keys ? (total < cap ? total : cap) : 0;
+  uint64_t *dk = keys, *dc = counts;
+  if (!on_device && m) { if (dmalloc(&dk, m) || dmalloc(&dc, m)) return SHK_ERR_HIP; }
+  c->h_pinned[46] = ~0ULL;
+  HIPCHK(hipMemcpyAsync(stop, c->h_pinned + 46, 8, hipMemcpyHostToDevice, c->stream));
+  if (total) {
+    ProfScope ps(c, KP_MISC);
+    unsigned long long *sp = ref_iterator_end ? stop : nullptr;
+    if (c->big_image) hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
+    else hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 46, stop, 8, hipMemcpyDeviceToHost, c->stream));
+  if (!on_device && m) {
+    HIPCHK(hipMemcpyAsync(keys, dk, m * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(counts, dc, m * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!on_device && m) { hipFree(dk); hipFree(dc); }
+  if (ref_iterator_end && c->h_pinned[46] < total) *n_out = c->h_pinned[46];
+  return finish(c, 0);
+}
+
+// dst := canonical table of (dst's entries + the second source's entries), counts of equal keys added
+static int merge2_run(shk_ctx *c, const ShkSrc2 &S, uint64_t *newd_out, uint64_t *added_out) {
+  ShkMergeArgs A;
+  uint64_t newd = 0, added = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    fill_args(c, &A, nullptr, 0, 0, 0, 0, 0);
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
+    c->spill_valid = 0;
+    { ProfScope ps(c, KP_MERGE_SUM);
+      if (c->big_image) hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S);
+      else hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S); }
+    { ProfScope ps(c, KP_REGION_SCAN);
+      const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
+      hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
+      hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
+      hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
+                         c->xnslots, (uint32_t)(c->big_image ? SHK_IMG_BLOCKS_BIG * 64 : SHK_IMG_SLOTS), c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t bits = 0;
+    if (fetch_err(c, &bits)) return SHK_ERR_HIP;
+    if (!c->big_image && (bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT)) && !(bits & SHK_E_TABLE_FULL)) { c->big_image = 1; c->last_err_bits = 0; continue; }
+    if (bits) return map_err_bits(bits);
+    newd = c->h_pinned[0]; added = c->h_pinned[1];
+    break;
+  }
+  HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
+  { ProfScope ps(c, KP_MERGE_WRITE);
+    if (c->big_image) hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S);
+    else hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S); }
+  HIPCHK(hipGetLastError());
+  c->cur ^= 1;
+  *newd_out = newd; *added_out = added;
+  return SHK_OK;
+}
+
+extern "C" int shk_merge(shk_ctx *dst, shk_ctx *src, shk_batch_stats *stats) {
+  if (!dst || !src || dst == src) return SHK_ERR_ARG;
+  if (dst->dev != src->dev || dst->cfg.qb != src->cfg.qb || dst->cfg.hb != src->cfg.hb || dst->q_lo != src->q_lo || dst->nslots != src->nslots)
+    return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(dst->dev));
+  HIPCHK(hipStreamSynchronize(src->stream));   // the source's table must be at rest
+  ShkSrc2 S;
+  memset(&S, 0, sizeof(S));
+  S.tab[0] = src->tab[src->cur]; S.fin[0] = src->fin[src->cur]; S.nblocks = src->nblocks; S.regions_per_src = dst->nregions; S.nsrc = 1;
+  uint64_t newd = 0, added = 0;
+  int rc = merge2_run(dst, S, &newd, &added);
+  if (!rc) {
+    dst->nelts += added; dst->ndistinct += newd;
+    if (stats) { memset(stats, 0, sizeof(*stats)); stats->kmers = added; stats->new_distinct = newd; }
+  }
+  return finish(dst, rc);
+}
+
+extern "C" int shk_multi_merge(shk_ctx *dst, shk_ctx *const *srcs, uint32_t n, shk_batch_stats *stats) {
+  if (!dst || (n && !srcs)) return SHK_ERR_ARG;
+  shk_batch_stats tot;
+  memset(&tot, 0, sizeof(tot));
+  for (uint32_t i = 0; i < n; i++) {
+    shk_batch_stats st;
+    int rc = shk_merge(dst, srcs[i], &st);
+    if (rc) return rc;
+    tot.kmers += st.kmers; tot.new_distinct += st.new_distinct;
+  }
+  if (stats) *stats = tot;
+  return SHK_OK;
+}
+
+// The whole filter from its quotient-range shards: shard s (a table in the layout shk_export_blocks gives for a context
+// with num_shards = nshards, shard_index = s: its nslots / nshards quotients plus its own overflow tail) supplies the
+// runs of its quotients; they are laid out again in the single table, where a cluster may now run across a shard border.
+extern "C" int shk_import_shards(shk_ctx *c, const void *const *shard_blocks, const uint64_t *shard_bytes, uint32_t nshards,
+                                 int on_device, uint64_t nelts, uint64_t ndistinct) {
+  if (!c || !shard_blocks || !shard_bytes || nshards == 0 || nshards > SHK_MAX_SRC || (nshards & (nshards - 1))) return SHK_ERR_ARG;
+  if (c->cfg.num_shards > 1 || c->q_lo != 0) return SHK_ERR_ARG;
+  const uint64_t s_nslots = c->nslots / nshards;
+  if (s_nslots < SHK_REGION || s_nslots % SHK_REGION) return SHK_ERR_ARG;
+  const uint64_t s_xnslots = s_nslots + (uint64_t)(10 * sqrt((double)c->g_nslots));
+  const uint64_t s_nblocks = (s_xnslots + 63) / 64, s_bytes = s_nblocks * SHK_BLOCK_BYTES;
+  const uint32_t s_nregions = (uint32_t)(s_nslots / SHK_REGION);
+  for (uint32_t s = 0; s < nshards; s++) if (shard_bytes[s] != s_bytes || !shard_blocks[s]) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  // start from an empty table
+  HIPCHK(hipMemsetAsync(c->tab[c->cur], 0, c->table_bytes + SHK_SLACK, c->stream));
+  HIPCHK(hipMemsetAsync(c->fin[c->cur], 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
+  c->nelts = 0; c->ndistinct = 0;
+  ShkSrc2 S;
+  memset(&S, 0, sizeof(S));
+  S.nblocks = s_nblocks; S.regions_per_src = s_nregions; S.nsrc = nshards;
+  std::vector<uint8_t *> own;
+  std::vector<uint64_t *> fins;
+  int rc = SHK_OK;
+  for (uint32_t s = 0; s < nshards && !rc; s++) {
+    uint8_t *dt = (uint8_t *)shard_blocks[s];
+    if (!on_device) {
+      if (dmalloc(&dt, s_bytes)) { rc = SHK_ERR_HIP; break; }
+      own.push_back(dt);
+      if (hipMemcpyAsync(dt, shard_blocks[s], s_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
+      if (hipMemsetAsync(dt + s_bytes, 0, SHK_SLACK, c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
+    }
+    uint64_t *df = nullptr;
+    if (dmalloc(&df, (uint64_t)s_nregions + 2)) { rc = SHK_ERR_HIP; break; }
+    fins.push_back(df);
+    hipLaunchKernelGGL(k_build_fin, dim3(s_nregions / 256 + 1), dim3(256), 0, c->stream, dt, s_nslots, s_nregions, df);
+    S.tab[s] = dt; S.fin[s] = df;
+  }
+  uint64_t newd = 0, added = 0;
+  if (!rc) rc = merge2_run(c, S, &newd, &added);
+  hipStreamSynchronize(c->stream);
+  for (auto p : own) hipFree(p);
+  for (auto p : fins) hipFree(p);
+  if (!rc) { c->nelts = nelts ? nelts : added; c->ndistinct = ndistinct ? ndistinct : newd; }
+  return finish(c, rc);
 }
 
 // ------------------------------------------------------------------ Contiger: seeds (processDataChunk, contig_assembly.cpp:1839-1884)

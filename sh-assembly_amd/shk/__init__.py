@@ -63,7 +63,7 @@ EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
-           "shk_last_error_bits"]
+           "shk_last_error_bits", "shk_insert_counted", "shk_dump", "shk_merge", "shk_multi_merge", "shk_import_shards"]
 
 _libs = {}
 
@@ -106,6 +106,11 @@ def load(path=None):
     L.shk_import_cqf.argtypes = [vp, C.c_char_p]
     L.shk_import_blocks.argtypes = [vp, vp, u64, u64, u64]
     L.shk_lookup.argtypes = [vp, vp, u64, i32, i32, vp, vp]
+    L.shk_insert_counted.argtypes = [vp, vp, vp, u64, i32, C.POINTER(BatchStats)]
+    L.shk_dump.argtypes = [vp, vp, vp, u64, i32, i32, pu64]
+    L.shk_merge.argtypes = [vp, vp, C.POINTER(BatchStats)]
+    L.shk_multi_merge.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(BatchStats)]
+    L.shk_import_shards.argtypes = [vp, C.POINTER(vp), pu64, u32, i32, u64, u64]
     L.shk_profile_enable.argtypes = [vp, i32]
     L.shk_profile_get.argtypes = [vp, C.POINTER(KernelTime), i32]
     L.shk_profile_reset.argtypes = [vp]
@@ -304,6 +309,47 @@ class Context:
         self._chk(self.L.shk_lookup(self.h, C.cast(k, C.c_void_p), n, 0, mode, C.cast(c, C.c_void_p),
                                     C.cast(t, C.c_void_p)))
         return [c[i] for i in range(n)], [t[i] for i in range(n)]
+
+    def insert_counted(self, keys, counts):
+        """add counts[i] occurrences of keys[i] (host lists); returns the batch statistics"""
+        n = len(keys)
+        k = (C.c_uint64 * max(n, 1))(*keys)
+        c = (C.c_uint64 * max(n, 1))(*counts)
+        st = BatchStats()
+        self._chk(self.L.shk_insert_counted(self.h, C.cast(k, C.c_void_p), C.cast(c, C.c_void_p), n, 0, C.byref(st)))
+        return st.as_dict()
+
+    def dump(self, ref_iterator_end=False):
+        """[(key, count)] in the order of the reference's iterator; ref_iterator_end: stop where its qfi_next stops"""
+        n = C.c_uint64()
+        self._chk(self.L.shk_dump(self.h, None, None, 0, 0, 0, C.byref(n)))
+        m = n.value
+        k = (C.c_uint64 * max(m, 1))()
+        c = (C.c_uint64 * max(m, 1))()
+        self._chk(self.L.shk_dump(self.h, C.cast(k, C.c_void_p), C.cast(c, C.c_void_p), m, 0, 1 if ref_iterator_end else 0,
+                                  C.byref(n)))
+        assert n.value <= m
+        return [(k[i], c[i]) for i in range(n.value)]
+
+    def merge(self, other):
+        """self += other (qf_merge)"""
+        st = BatchStats()
+        self._chk(self.L.shk_merge(self.h, other.h, C.byref(st)))
+        return st.as_dict()
+
+    def multi_merge(self, others):
+        st = BatchStats()
+        arr = (C.c_void_p * max(len(others), 1))(*[o.h for o in others])
+        self._chk(self.L.shk_multi_merge(self.h, arr, len(others), C.byref(st)))
+        return st.as_dict()
+
+    def import_shards(self, shard_blocks, nelts=0, ndistinct=0):
+        """replace the table by the union of the shards' tables (bytes objects, shard order)"""
+        n = len(shard_blocks)
+        bufs = [(C.c_char * len(b)).from_buffer_copy(b) for b in shard_blocks]
+        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+        sizes = (C.c_uint64 * n)(*[len(b) for b in shard_blocks])
+        self._chk(self.L.shk_import_shards(self.h, ptrs, sizes, n, 0, nelts, ndistinct))
 
     def profile(self, on=True):
         self._chk(self.L.shk_profile_enable(self.h, 1 if on else 0))

@@ -112,6 +112,14 @@ class _QF:
                             1 if end_denoise else 0, part_size, overhead, min_len, st)
         return {"rounds": st[0], "removed": st[1], "chunks": st[2]}
 
+    def merge_from(self, a, b):
+        """self := a + b through the reference's qf_merge (ref only; self must be empty)"""
+        self._f("qf_merge")(a.h, b.h, self.h)
+
+    def multi_merge_from(self, qs):
+        arr = (C.c_void_p * len(qs))(*[q.h for q in qs])
+        self._f("qf_multi_merge")(arr, len(qs), self.h)
+
     def full(self):
         return bool(self.L.orc_qf_full(self.h)) if self.p == "orc_" else False
 
@@ -162,6 +170,9 @@ class _Lib:
                                           C.POINTER(i32), C.POINTER(C.c_uint8)])
         if p == "ref_":
             sig("encode_counter", i32, [vp, u64, u64, C.POINTER(u64)])
+            if hasattr(L, "ref_qf_merge"):
+                sig("qf_merge", None, [vp, vp, vp])
+                sig("qf_multi_merge", None, [C.POINTER(vp), i32, vp])
             if hasattr(L, "ref_time_chunks_mt"):   # (a prebuilt oracle/_ref from before this entry existed lacks it)
                 sig("time_chunks_mt", C.c_double, [vp, C.c_char_p, C.POINTER(u64), C.POINTER(u64), u32, C.c_uint, C.c_uint,
                                                    C.c_double, C.POINTER(u64), C.POINTER(u32)])

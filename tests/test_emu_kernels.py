@@ -384,3 +384,25 @@ def test_find_unitigs_rebuilds_an_error_free_genome(shk, tmp_path):
         assert s in gs or _rc(s) in gs
     assert max(len(s) for s in got) >= 150
 
+
+
+def test_counted_insert_dump_merge_shards(shk):
+    """f-4 / a-9 on the emulator build: counted inserts, iterator dump, qf_merge / qf_multi_merge and the shard stitch
+    against the compiled reference (tests/f4_scenarios.py); tiny tables incl. dense clusters and saturated offsets"""
+    import random
+    import f4_scenarios as F
+
+    def mk(qb):
+        return _ctx(shk, qb=qb, k=21, max_batch_keys=1 << 14)
+
+    def mk_shard(qb, s, n):
+        return _ctx(shk, qb=qb, k=21, max_batch_keys=1 << 14, shard_index=s, num_shards=n)
+    rng = random.Random(11)
+    # (few and small cases: every workgroup thread is an OS thread here; tests/test_gpu_parity.py runs the full set)
+    F.check_counted_and_dump(mk, 10, F.pairs(rng, 10, 120, 1 << 14, cluster=(700, 90)))      # a long cluster: offsets saturate
+    F.check_counted_and_dump(mk, 10, F.pairs(rng, 10, 60, 300, cluster=(1000, 24)), batches=2)  # runs spill into the tail
+    a = F.pairs(rng, 10, 100, 400, cluster=(300, 60))
+    b = [(k, c + 1) for k, c in a[:50]] + F.pairs(rng, 10, 60, 400, cluster=(310, 60))   # shared keys: counts add
+    b = list({k: c for k, c in b}.items())
+    F.check_merge(mk, 10, [a, b, F.pairs(rng, 10, 90, 1 << 12)])
+    F.check_shards(mk, mk_shard, 10, F.pairs(rng, 10, 140, 300, cluster=(480, 64)), 2)   # a cluster across the shard border

@@ -473,3 +473,120 @@ def test_randomised_configurations_match_oracle():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert "0 mismatches" in r.stdout
+
+
+# ---------------------------------------------------------------- f-4 / a-9: counted inserts, dump, merge, shard stitch
+def _f4_makers():
+    def mk(qb):
+        return _ctx(qb=qb, k=21, max_batch_keys=1 << 22)
+
+    def mk_shard(qb, s, n):
+        return _ctx(qb=qb, k=21, max_batch_keys=1 << 22, shard_index=s, num_shards=n)
+    return mk, mk_shard
+
+
+def test_counted_insert_and_dump_match_reference():
+    """shk_insert_counted == qf_insert_advance(count) of the compiled reference (gqf.c:2024-2136), byte for byte, incl.
+    counts up to 2^35 (several passes of 2^22 occurrences), codec edge remainders, dense clusters, the overflow tail;
+    shk_dump == the reference's iterator (gqf.c:2474-2601), incl. where it stops early"""
+    import random
+    import f4_scenarios as F
+    mk, _ = _f4_makers()
+    rng = random.Random(5)
+    F.check_counted_and_dump(mk, 12, F.pairs(rng, 12, 1000, 1 << 20))
+    F.check_counted_and_dump(mk, 14, F.pairs(rng, 14, 4000, 1 << 24))
+    F.check_counted_and_dump(mk, 12, F.pairs(rng, 12, 900, 1 << 16, cluster=(2000, 300)))     # offsets saturate at 255
+    F.check_counted_and_dump(mk, 12, F.pairs(rng, 12, 150, 1 << 16, cluster=(4000, 96)))      # runs end in the tail (not near its end:
+    # the reference's 8-byte slot accesses overrun its buffer there)
+    F.check_counted_and_dump(mk, 10, F.pairs(rng, 10, 40, 1 << 35), batches=2)                # > 2^32 per key
+    # more distinct new keys in one 256-quotient region than its LDS hash holds: the call splits its pairs
+    dense = [((1024 + i % 256) << 8 | (i * 37 + (i // 256) * 11) % 256, 1 + i % 2) for i in range(0, 1300)]
+    dense = list({k: c for k, c in dense}.items())
+    assert len(dense) > 1000
+    F.check_counted_and_dump(mk, 12, dense, batches=1)
+
+
+def test_merge_matches_reference_qf_merge():
+    """shk_merge / shk_multi_merge == the compiled qf_merge / qf_multi_merge (gqf.c:2614-2704): table bytes, dump, counters"""
+    import random
+    import f4_scenarios as F
+    mk, _ = _f4_makers()
+    rng = random.Random(6)
+    F.check_merge(mk, 12, [F.pairs(rng, 12, 400, 1 << 16), F.pairs(rng, 12, 500, 1 << 16), F.pairs(rng, 12, 300, 1 << 16)])
+    a = F.pairs(rng, 14, 1500, 1 << 12, cluster=(3000, 4000))
+    b = [(k, c + 3) for k, c in a[::2]] + F.pairs(rng, 14, 800, 1 << 12, cluster=(3500, 4000))   # one long cluster: the big LDS image
+    b = list({k: c for k, c in b}.items())
+    F.check_merge(mk, 14, [a, b])
+    F.check_merge(mk, 16, [F.pairs(rng, 16, 8000, 1 << 10), F.pairs(rng, 16, 7000, 1 << 10), F.pairs(rng, 16, 4000, 300),
+                           F.pairs(rng, 16, 2000, 300)])
+
+
+def test_merge_of_tail_entries():
+    """The reference's qfi_next reports "end" when it steps inside a run onto a slot behind nslots (gqf.c:2537-2539);
+    qf_merge's drain loops stop there, so it can lose entries of its inputs' overflow tails. shk_merge adds everything
+    the source holds: its result is the canonical table of the union, and the reference's result is contained in it,
+    differing only by tail entries."""
+    import random
+    import f4_scenarios as F
+    if not cqflibs.have_ref():
+        pytest.skip("needs oracle/_ref")
+    lib = cqflibs.ref()
+    mk, _ = _f4_makers()
+    rng = random.Random(8)
+    qb = 10
+    a = F.pairs(rng, qb, 80, 300, cluster=(1000, 24))          # quotients 1000..1023: the last runs lie in the tail
+    b = F.pairs(rng, qb, 60, 300, cluster=(0, 900))
+    qa, qb_ = F.build(lib, qb, a), F.build(lib, qb, b)
+    assert len(qa.dump()) < len(a), "scenario must produce entries the reference iterator does not reach"
+    want = lib.new(qb)
+    want.merge_from(qa, qb_)
+    ca, cb, dst, rc = mk(qb), mk(qb), mk(qb), mk(qb)
+    ca.insert_counted([k for k, _ in a], [c for _, c in a])
+    cb.insert_counted([k for k, _ in b], [c for _, c in b])
+    dst.merge(ca)
+    dst.merge(cb)
+    union = F.build(cqflibs.oracle(), qb, a + b)
+    assert dst.blocks() == union.blocks()
+    rc.import_blocks(want.blocks())
+    ref_has, ours = dict(rc.dump()), dict(dst.dump())
+    assert all(ours.get(k) == c for k, c in ref_has.items())          # what the reference merged is there, same counts
+    lost = [k for k in ours if k not in ref_has]
+    assert lost and all((k >> 8) >= 1000 for k in lost)               # and it lost only entries of the tail cluster
+    for x in (ca, cb, dst, rc):
+        x.close()
+    for x in (qa, qb_, want, union):
+        x.free()
+
+
+def test_import_shards_equals_single_table():
+    """quotient-range shards (own overflow tails) stitched on the device == the single table, incl. clusters that cross
+    shard borders and a shard whose last runs lie in its tail"""
+    import random
+    import f4_scenarios as F
+    mk, mk_shard = _f4_makers()
+    rng = random.Random(9)
+    F.check_shards(mk, mk_shard, 12, F.pairs(rng, 12, 1200, 1 << 12), 2)
+    F.check_shards(mk, mk_shard, 14, F.pairs(rng, 14, 5000, 1 << 12), 8)
+    F.check_shards(mk, mk_shard, 12, F.pairs(rng, 12, 400, 300, cluster=(1900, 300)), 2)     # cluster across the border at 2048
+    F.check_shards(mk, mk_shard, 12, F.pairs(rng, 12, 900, 300, cluster=(500, 3000)), 4)
+    F.check_shards(mk, mk_shard, 13, F.pairs(rng, 13, 2200, 300, cluster=(1000, 7000)), 8)
+
+
+def test_build_then_dump_then_rebuild_is_identity():
+    """a filter built from reads, dumped and re-inserted with counts gives the same bytes (qf_insert_advance(count)
+    == count single inserts), and its dump equals the oracle's"""
+    g = synth.make_genome(30000, 3)
+    fq = synth.make_fastq(g, 4000, 120, 0.01, seed=4, n_frac=0.02)
+    offs, lens = chunks_by_records(fq, 500)
+    ctx = _ctx(qb=18, k=31, max_batch_bytes=len(fq) + 1024, max_batch_keys=1 << 20)
+    ctx.count_chunks(fq, offs, lens)
+    q, _, _ = oracle_t1(fq, offs, lens, 31, 18)
+    d = ctx.dump()
+    assert d == q.dump()
+    again = _ctx(qb=18, k=31, max_batch_keys=1 << 20)
+    st = again.insert_counted([k for k, _ in d], [c for _, c in d])
+    assert st["new_distinct"] == len(d) and st["kmers"] == q.nelts()
+    assert again.blocks() == ctx.blocks() == q.blocks()
+    for x in (ctx, again):
+        x.close()
+    q.free()
