@@ -163,6 +163,12 @@ def main():
     default_workload = (args.reads_per_step == 8_000_000 and args.genome == 119_157_843 and args.qb == 0 and not args.ablate
                         and args.gpus == 1 and not args.host_text)
 
+    # stdout carries exactly ONE line (the JSON): libraries that chat on file descriptor 1 (RCCL prints a version
+    # banner there when a process group starts) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import shk
     from shk import plan
@@ -226,6 +232,12 @@ def main():
             self.sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
             self.counted = self.removed = self.rounds = 0
             self.uploaded = {}
+            self.inflight = {}
+
+        def exchange(self, s):
+            t = texts[s]
+            _, nw = self.ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
+            return shkdist.Exchange(self.ctx, nw, hb, world, rank, device)
 
         def step(self, s, nsteps):
             ctx, t = self.ctx, texts[s]
@@ -241,11 +253,19 @@ def main():
                 else:
                     st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
             else:
-                dp, nw = ctx.hash_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
-                recv = shkdist.route_words(ctx, nw, hb, world, rank, device)
-                torch.cuda.synchronize()
+                # pipelined: the all-to-all of batch s was started one step ago; before waiting for it, batch s+1 is
+                # hashed, binned by owner (second send buffer) and ITS exchange started -- xGMI moves key words while
+                # the CUs stage and insert batch s
+                if s not in self.inflight:
+                    self.inflight[s] = self.exchange(s)
+                ex = self.inflight.pop(s)
+                if s + 1 < nsteps:
+                    self.inflight[s + 1] = self.exchange(s + 1)
+                recv = ex.wait()
                 ctx.stage_words(recv.data_ptr(), recv.numel())
                 st = shkdist.sharded_count(ctx, self.sstate, len(offs) * world)   # counts are whole-job (all-reduced)
+                if s + 1 == nsteps:
+                    shkdist.check(ctx, self.sstate)
             self.counted += st["kmers"]
             self.removed += st["removed"]
             self.rounds += st["denoise_rounds"]
@@ -260,6 +280,8 @@ def main():
         w = Run()
         for s in range(args.warmup):
             w.step(s % args.steps, args.steps)
+        for ex in w.inflight.values():     # (the exchange a pipelined warm-up step started for a batch it never counted)
+            ex.wait()
         torch.cuda.synchronize()
         w.ctx.close()
         del w
@@ -342,7 +364,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             text_cpu = texts[0].cpu().numpy().tobytes()
             out["cpu_baseline"] = cpu_baseline(torch, text_cpu, offs, lens, K, qb)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist:
         dist.destroy_process_group()

@@ -150,7 +150,8 @@ typedef struct shk_summary {
 #define SHK_HASH_FULL_BIT 0x04u /* too many distinct new keys in one region: summarise fewer chunks */
 /* Group the key words left by shk_hash_chunks by owner shard (owner = top log2(nshards) bits of
  * the quotient): `*d_out` (context-owned, valid until the next call) holds them owner by owner,
- * counts[o] words for owner o -- the send buffer of the all-to-all. */
+ * counts[o] words for owner o -- the send buffer of the all-to-all. Two send buffers alternate: the result of one
+ * call stays valid until the SECOND-next call, so batch s can be on the wire while batch s+1 is hashed and routed. */
 int shk_route_words(shk_ctx *ctx, uint64_t nwords, uint32_t nshards, uint64_t **d_out, uint64_t *counts);
 int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
@@ -209,6 +210,8 @@ int shk_stats(shk_ctx *ctx, shk_totals *out);
 int shk_header(shk_ctx *ctx, uint8_t out[128]);
 /* table bytes (nblocks * 89) to host memory */
 int shk_export_blocks(shk_ctx *ctx, void *host_dst, uint64_t cap);
+/* device pointer and size of the live table (valid until the next call that rebuilds the table) */
+int shk_table_ptr(shk_ctx *ctx, void **d_table, uint64_t *nbytes);
 /* header + blocks, byte-identical to qf_serialize */
 int shk_export_cqf(shk_ctx *ctx, const char *path);
 /* replace the table by one read from a .cqf (whole filter; num_shards must be 1) */

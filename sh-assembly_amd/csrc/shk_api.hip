@@ -99,6 +99,8 @@ struct shk_ctx {
   double new_frac;              // new distinct keys per presented k-mer in the last committed range (predicts crossings)
   int staged;                   // which d_words[] holds the partitioned words of shk_stage_words
   int counted;                  // 1 while shk_insert_counted runs: the words' chunk field is a multiplicity
+  uint64_t *d_send[2];          // shk_route_words: two alternating send buffers (allocated on first use), so that the
+  int send_next;                // exchange of one batch can run while the next batch is hashed and routed
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libshk: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return SHK_ERR_HIP; } } while (0)
@@ -278,7 +280,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   }
   prof_collect(c);
   for (size_t i = 0; i < c->evpool.size(); i++) hipEventDestroy(c->evpool[i]);
-  for (int i = 0; i < 2; i++) { hipFree(c->tab[i]); hipFree(c->fin[i]); hipFree(c->d_words[i]); }
+  for (int i = 0; i < 2; i++) { hipFree(c->tab[i]); hipFree(c->fin[i]); hipFree(c->d_words[i]); if (c->d_send[i]) hipFree(c->d_send[i]); }
   hipFree(c->d_text); hipFree(c->d_chunk_off); hipFree(c->d_chunk_len); hipFree(c->d_nlines); hipFree(c->d_reads_base);
   hipFree(c->d_rd_start); hipFree(c->d_rd_end); hipFree(c->d_rd_chunk); hipFree(c->d_nkeys); hipFree(c->d_key_base); hipFree(c->d_scalars);
   hipFree(c->d_block_sums);
@@ -890,7 +892,18 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   HIPCHK(hipSetDevice(c->dev));
   uint32_t lg = 0;
   while ((1u << lg) < nshards) lg++;
-  if (lg == 0) { *d_out = c->d_words[0]; counts[0] = nwords; return SHK_OK; }
+  uint64_t *send = c->d_words[1];
+  if (!getenv("SHK_ROUTE_SINGLE_BUFFER")) {
+    const int b = c->send_next;
+    if (!c->d_send[b] && dmalloc(&c->d_send[b], c->cfg.max_batch_keys + 1)) return SHK_ERR_HIP;
+    send = c->d_send[b];
+    c->send_next ^= 1;
+  }
+  if (lg == 0) {
+    HIPCHK(hipMemcpyAsync(send, c->d_words[0], nwords * 8, hipMemcpyDeviceToDevice, c->stream));
+    *d_out = send; counts[0] = nwords;
+    return finish(c, 0);
+  }
   if (c->cfg.qb < SHK_REGION_LOG2 + lg) return SHK_ERR_ARG;
   // one partition level over the WHOLE filter's regions: digit = owner
   ShkRpLevel lv;
@@ -919,10 +932,10 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   HIPCHK(hipMemcpyAsync(cursor, bb.data(), nshards * 8, hipMemcpyHostToDevice, c->stream));
   (void)base;
   { ProfScope ps(c, KP_RP_SCATTER);
-    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], c->d_words[1], n_p,
+    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], send, n_p,
                        c->d_base[0], c->d_tfb, lv, cursor, c->d_err); }
   HIPCHK(hipGetLastError());
-  *d_out = c->d_words[1];
+  *d_out = send;
   return finish(c, 0);
 }
 
@@ -1079,6 +1092,16 @@ extern "C" int shk_export_blocks(shk_ctx *c, void *dst, uint64_t cap) {
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipMemcpyAsync(dst, c->tab[c->cur], c->table_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return SHK_OK;
+}
+
+// device pointer and size of the live table (valid until the next call that rebuilds it): lets a caller move a
+// shard's table to the GPU that stitches them without a trip through host memory
+extern "C" int shk_table_ptr(shk_ctx *c, void **d_table, uint64_t *nbytes) {
+  if (!c || !d_table || !nbytes) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *d_table = c->tab[c->cur]; *nbytes = c->table_bytes;
   return SHK_OK;
 }
 

@@ -63,7 +63,7 @@ EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
-           "shk_last_error_bits", "shk_insert_counted", "shk_dump", "shk_merge", "shk_multi_merge", "shk_import_shards"]
+           "shk_last_error_bits", "shk_insert_counted", "shk_dump", "shk_merge", "shk_multi_merge", "shk_import_shards", "shk_table_ptr"]
 
 _libs = {}
 
@@ -111,6 +111,7 @@ def load(path=None):
     L.shk_merge.argtypes = [vp, vp, C.POINTER(BatchStats)]
     L.shk_multi_merge.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(BatchStats)]
     L.shk_import_shards.argtypes = [vp, C.POINTER(vp), pu64, u32, i32, u64, u64]
+    L.shk_table_ptr.argtypes = [vp, C.POINTER(vp), pu64]
     L.shk_profile_enable.argtypes = [vp, i32]
     L.shk_profile_get.argtypes = [vp, C.POINTER(KernelTime), i32]
     L.shk_profile_reset.argtypes = [vp]
@@ -136,6 +137,7 @@ class Context:
                  max_batch_keys=1 << 26, max_batch_reads=0, device=0, shard_index=0, num_shards=1, seed=2038074761,
                  threads_per_group=0, hash_groups=0, max_level_bits=0, lib_path=None):
         self.L = load(lib_path)
+        self.lib_path = lib_path
         self.cfg = Config(qb=qb, hb=qb + 8, seed=seed, k=k, ndistinct_for_denoise=trigger, num_denoise=num_denoise,
                           min_denoise_len=min_denoise_len, max_batch_bytes=max_batch_bytes,
                           max_batch_keys=max_batch_keys, max_batch_reads=max_batch_reads, device=device,
@@ -350,6 +352,19 @@ class Context:
         ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
         sizes = (C.c_uint64 * n)(*[len(b) for b in shard_blocks])
         self._chk(self.L.shk_import_shards(self.h, ptrs, sizes, n, 0, nelts, ndistinct))
+
+    def table_ptr(self):
+        """(device pointer, bytes) of the live table"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.shk_table_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def import_shards_device(self, ptrs, nbytes, nelts=0, ndistinct=0):
+        """like import_shards, from tables that already live on this context's device (16 readable bytes behind each)"""
+        n = len(ptrs)
+        arr = (C.c_void_p * n)(*ptrs)
+        sizes = (C.c_uint64 * n)(*([nbytes] * n))
+        self._chk(self.L.shk_import_shards(self.h, arr, sizes, n, 1, nelts, ndistinct))
 
     def profile(self, on=True):
         self._chk(self.L.shk_profile_enable(self.h, 1 if on else 0))

@@ -4,13 +4,22 @@
 key words it OWNS (routing is the caller's all-to-all), and the ranks take the deNoise decision
 together on all-reduced statistics, so a round fires after the same global chunk on every
 shard -- the chunk at which the whole filter's distinct count reaches the trigger
-(cqf/CQF_mt.h:837, 860-869). Works with RCCL ("nccl") on GPUs and with gloo on the CPU."""
+(cqf/CQF_mt.h:837, 860-869). Works with RCCL ("nccl") on GPUs and with gloo on the CPU.
+
+Collectives per batch: ONE all-to-all of key words (8 B per routed key over xGMI) and ONE small
+all-reduce per decision (statistics, kernel flag bits and the ranks' local return codes travel in
+the same vector; a batch without a deNoise point takes one decision). A rank-local failure is
+therefore seen by every rank at the next decision and raised everywhere -- no rank is left
+waiting in a collective its peers never enter."""
 import os
 
 import torch
 import torch.distributed as dist
 
-from . import HASH_FULL_BIT, HIST_BINS, LOOKBACK_BIT, SOFT_BITS, ShkError
+from . import HASH_FULL_BIT, HIST_BINS, LOOKBACK_BIT, SOFT_BITS, ShkError, Summary
+
+NBITS = 9        # kernel flag bits (csrc/shk_device.h SHK_E_*)
+NCODES = 8       # SHK_ERR_* codes -1 .. -8 (include/shk.h)
 
 
 class ShardState:
@@ -21,35 +30,95 @@ class ShardState:
         self.ndistinct = 0          # whole filter
         self.nelts = 0
         self.device = device
+        self.pending_rc = 0         # return code of a rank-local call not yet shown to the peers
+        self.collectives = 0        # small all-reduces issued (diagnostics)
 
 
-def _allreduce(vals, device, op=None):
-    t = torch.tensor(vals, dtype=torch.int64, device=device)
+def _allreduce(vals, st, op=None):
+    t = torch.tensor(vals, dtype=torch.int64, device=st.device)
     dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
+    st.collectives += 1
     return [int(x) for x in t.tolist()]
 
 
-def _summary(ctx, st, lo, hi, base, shift, want_hist, single=False):
-    """local summary (or single-launch try) + reduction; returns
-    (newd, before, hist[], hard_bits_any, hash_full_any, soft_any, local)"""
-    s = ctx.stage_try(lo, hi, base, shift, want_hist) if single else ctx.stage_summary(lo, hi, base, shift, want_hist)
-    red = _allreduce([s.new_distinct, s.before] + list(s.hist), st.device)
-    flags = _allreduce([s.err_bits & ~(SOFT_BITS | HASH_FULL_BIT | LOOKBACK_BIT) & 0xFFFFFFFF,
-                        s.err_bits & (HASH_FULL_BIT | LOOKBACK_BIT), s.err_bits & SOFT_BITS], st.device, dist.ReduceOp.MAX)
-    return red[0], red[1], red[2:], flags[0], flags[1], flags[2], s
+def _local(st, call, default=None):
+    """run a rank-local library call; a failure is remembered (not raised) until the next decision"""
+    try:
+        return call()
+    except ShkError as e:
+        if not st.pending_rc:
+            st.pending_rc = e.code
+        return default
 
 
-def _exact_point(ctx, st, lo, hi):
-    """global chunk at which the filter-wide distinct count reaches the trigger, from the exact
-    per-chunk histograms of the pass just run with want_hist=2 (None when a rank has none)"""
-    h = ctx.stage_chunk_hist(hi + 1)
-    ok = _allreduce([0 if h is None else 1], st.device, dist.ReduceOp.MIN)[0]
-    if not ok:
-        return None
-    t = torch.tensor(h[lo:hi + 1], dtype=torch.int64, device=st.device)
-    dist.all_reduce(t)
+class _Decision:
+    """statistics of one try/summary on every rank, reduced: sums of the counters, OR of the flag bits"""
+    __slots__ = ("newd", "before", "added", "removed", "hist", "chist", "bits", "local")
+
+    @property
+    def hard(self):
+        return self.bits & ~(SOFT_BITS | HASH_FULL_BIT | LOOKBACK_BIT) & 0xFFFFFFFF
+
+    @property
+    def hfull(self):
+        return self.bits & (HASH_FULL_BIT | LOOKBACK_BIT)
+
+    @property
+    def soft(self):
+        return self.bits & SOFT_BITS
+
+
+def _decide(ctx, st, call, chist_range=None, extra=None):
+    """`call` -> Summary on this rank; ONE all-reduce carries its counters, its flag bits (one entry per bit), the
+    exact first-chunk histogram of [lo, hi] when asked for (plus a "have it" count), and this rank's pending return
+    code (one entry per code). Raises the same ShkError on every rank when any rank failed."""
+    s = _local(st, call, None)
+    if s is None:
+        s = Summary()
+    vec = [s.new_distinct, s.before, s.added, s.removed] + list(s.hist)
+    vec += [(s.err_bits >> b) & 1 for b in range(NBITS)]
+    vec += [1 if st.pending_rc == -c else 0 for c in range(1, NCODES + 1)]
+    nch = 0
+    if chist_range is not None:
+        lo, hi = chist_range
+        h = _local(st, lambda: ctx.stage_chunk_hist(hi + 1), None) if not st.pending_rc else None
+        nch = hi - lo + 1
+        vec += [0 if h is None else 1] + ([0] * nch if h is None else list(h[lo:hi + 1]))
+    if extra:
+        vec += list(extra)
+    red = _allreduce(vec, st)
+    codes = red[4 + HIST_BINS + NBITS: 4 + HIST_BINS + NBITS + NCODES]
+    for c in range(1, NCODES + 1):
+        if codes[c - 1]:
+            st.pending_rc = 0
+            raise ShkError(-c, "%s (on %d of the ranks)" % (ctx.L.shk_strerror(-c).decode(), codes[c - 1]))
+    d = _Decision()
+    d.newd, d.before, d.added, d.removed = red[0:4]
+    d.hist = red[4:4 + HIST_BINS]
+    d.bits = sum(1 << b for b in range(NBITS) if red[4 + HIST_BINS + b])
+    d.local = s
+    d.chist = None
+    if chist_range is not None:
+        base = 4 + HIST_BINS + NBITS + NCODES
+        if red[base] == dist.get_world_size():
+            d.chist = red[base + 1: base + 1 + nch]
+    return d
+
+
+def check(ctx, st):
+    """make a rank-local failure of the last calls (accept/commit of the final batch) known everywhere; call once
+    after the last batch"""
+    red = _allreduce([1 if st.pending_rc == -c else 0 for c in range(1, NCODES + 1)], st)
+    for c in range(1, NCODES + 1):
+        if red[c - 1]:
+            st.pending_rc = 0
+            raise ShkError(-c, "%s (on %d of the ranks)" % (ctx.L.shk_strerror(-c).decode(), red[c - 1]))
+
+
+def _point(st, d, lo, hi):
+    """global chunk at which the filter-wide distinct count reaches the trigger (exact histogram of [lo, hi])"""
     run = st.ndistinct
-    for i, v in enumerate(t.tolist()):
+    for i, v in enumerate(d.chist):
         run += v
         if run >= st.trigger:
             return lo + i
@@ -59,45 +128,54 @@ def _exact_point(ctx, st, lo, hi):
 def sharded_count(ctx, st, nchunks):
     """insert the staged words of global chunks [0, nchunks); returns dict(kmers, new_distinct, removed, rounds)"""
     out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
+
+    def book(d):
+        st.ndistinct += d.newd
+        st.nelts += d.added
+        out["kmers"] += d.added
+        out["new_distinct"] += d.newd
+
+    def fail(d):
+        bits = d.hard | d.hfull | d.soft
+        _local(st, lambda: ctx.error_for_bits(bits))
+        check(ctx, st)          # every rank raises here (the bits are the same everywhere)
+
     lo = 0
     while lo < nchunks:
         hi = nchunks - 1
         watch = st.rounds_left > 0
-        # common case: one try per rank does statistics (and, in the single-launch scheme, the table);
-        # accepted when no rank saw an error and the whole filter stays below the trigger. While rounds
-        # are left the try also records first chunks, so a deNoise point is located without more passes.
-        newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, 2 if watch else 0, single=True)
-        if hard:
-            ctx.error_for_bits(hard)
-        crosses = watch and st.ndistinct + newd >= st.trigger
-        if not (hfull or soft) and not crosses:
-            ctx.stage_accept(loc)
-            added = _allreduce([loc.added], st.device)[0]
-            st.ndistinct += newd
-            st.nelts += added
-            out["kmers"] += added
-            out["new_distinct"] += newd
+        # common case: one try per rank does statistics (and, in the single-launch scheme, the table); accepted when
+        # no rank saw an error and the whole filter stays below the trigger. While rounds are left the try also
+        # records first chunks and their histogram rides along, so a deNoise point is located without more passes.
+        d = _decide(ctx, st, lambda: ctx.stage_try(lo, hi, lo, 0, 2 if watch else 0), (lo, hi) if watch else None)
+        if d.hard:
+            fail(d)
+        crosses = watch and st.ndistinct + d.newd >= st.trigger
+        if not (d.hfull or d.soft) and not crosses:
+            _local(st, lambda: ctx.stage_accept(d.local))
+            book(d)
             lo = hi + 1
             continue
-        point = _exact_point(ctx, st, lo, hi) if (crosses and not hfull) else None
+        point = _point(st, d, lo, hi) if (crosses and not d.hfull and d.chist is not None) else None
+        shift = 0
         if point is None:
             while True:
                 span = hi - lo + 1
                 shift = 0
                 while ((span + (1 << shift) - 1) >> shift) > HIST_BINS:
                     shift += 1
-                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, 2 if watch else 0)
-                if hard:
-                    ctx.error_for_bits(hard)
-                if hfull:
+                d = _decide(ctx, st, lambda: ctx.stage_summary(lo, hi, lo, shift, 2 if watch else 0), (lo, hi) if watch else None)
+                if d.hard:
+                    fail(d)
+                if d.hfull:
                     if hi == lo:
-                        ctx.error_for_bits(HASH_FULL_BIT)
+                        fail(d)
                     hi = lo + (hi - lo) // 2
                     continue
                 break
-            crosses = watch and st.ndistinct + newd >= st.trigger
-            if crosses:
-                point = _exact_point(ctx, st, lo, hi)
+            crosses = watch and st.ndistinct + d.newd >= st.trigger
+            if crosses and d.chist is not None:
+                point = _point(st, d, lo, hi)
         fire = False
         accepted = False
         if crosses:
@@ -106,16 +184,16 @@ def sharded_count(ctx, st, nchunks):
             else:
                 # 32-bin refinement (contexts without the exact histogram)
                 base = lo
-                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, shift, True)
-                if hard:
-                    ctx.error_for_bits(hard)
+                d = _decide(ctx, st, lambda: ctx.stage_summary(lo, hi, lo, shift, True))
+                if d.hard:
+                    fail(d)
                 while True:
-                    run = st.ndistinct + before
+                    run = st.ndistinct + d.before
                     b = 0
                     while b < HIST_BINS:
-                        if run + hist[b] >= st.trigger:
+                        if run + d.hist[b] >= st.trigger:
                             break
-                        run += hist[b]
+                        run += d.hist[b]
                         b += 1
                     b = min(b, HIST_BINS - 1)
                     b_lo = base + (b << shift)
@@ -128,25 +206,21 @@ def sharded_count(ctx, st, nchunks):
                     while ((span2 + (1 << shift) - 1) >> shift) > HIST_BINS:
                         shift += 1
                     base = b_lo
-                    newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, b_hi, base, shift, True)
-                    if hard:
-                        ctx.error_for_bits(hard)
+                    d = _decide(ctx, st, lambda: ctx.stage_summary(lo, b_hi, base, shift, True))
+                    if d.hard:
+                        fail(d)
             fire = True
-            newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False, single=True)
-            if not (hard or hfull or soft):
-                ctx.stage_accept(loc)
+            d = _decide(ctx, st, lambda: ctx.stage_try(lo, hi, lo, 0, 0))
+            if not (d.hard or d.hfull or d.soft):
+                _local(st, lambda: ctx.stage_accept(d.local))
                 accepted = True
             else:
-                newd, before, hist, hard, hfull, soft, loc = _summary(ctx, st, lo, hi, lo, 0, False)
-        if hard or hfull or soft:
-            ctx.error_for_bits(hard | hfull | soft)
+                d = _decide(ctx, st, lambda: ctx.stage_summary(lo, hi, lo, 0, 0))
+        if d.hard or d.hfull or d.soft:
+            fail(d)
         if not accepted:
-            ctx.stage_commit(lo, hi, loc)
-        added = _allreduce([loc.added], st.device)[0]
-        st.ndistinct += newd
-        st.nelts += added
-        out["kmers"] += added
-        out["new_distinct"] += newd
+            _local(st, lambda: ctx.stage_commit(lo, hi, d.local))
+        book(d)
         if fire:
             st.rounds_left -= 1
             st.rounds_done += 1
@@ -155,36 +229,43 @@ def sharded_count(ctx, st, nchunks):
             if hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
                 # one pass: drop the singletons and insert the chunks behind the deNoise point; taken when no rank
                 # objects and the trigger is not reached again inside the rest
-                loc = ctx.stage_try_denoise(hi + 1, nchunks - 1)
-                red = _allreduce([loc.new_distinct, loc.removed, loc.added], st.device)
-                bad = _allreduce([1 if loc.err_bits else 0], st.device, dist.ReduceOp.MAX)[0]
-                again = st.rounds_left > 0 and st.ndistinct - red[1] + red[0] >= st.trigger
-                if not bad and not again:
-                    ctx.stage_accept(loc)
-                    st.ndistinct += red[0] - red[1]
-                    st.nelts += red[2] - red[1]
-                    out["removed"] += red[1]
-                    out["kmers"] += red[2]
-                    out["new_distinct"] += red[0]
+                d = _decide(ctx, st, lambda: ctx.stage_try_denoise(hi + 1, nchunks - 1))
+                again = st.rounds_left > 0 and st.ndistinct - d.removed + d.newd >= st.trigger
+                if not d.bits and not again:
+                    _local(st, lambda: ctx.stage_accept(d.local))
+                    st.ndistinct += d.newd - d.removed
+                    st.nelts += d.added - d.removed
+                    out["removed"] += d.removed
+                    out["kmers"] += d.added
+                    out["new_distinct"] += d.newd
                     fused = True
                     hi = nchunks - 1
             if not fused:
-                removed = _allreduce([ctx.denoise()], st.device)[0]
-                st.ndistinct -= removed
-                st.nelts -= removed
-                out["removed"] += removed
+                r = _local(st, ctx.denoise, 0)
+                red = _allreduce([r] + [1 if st.pending_rc == -c else 0 for c in range(1, NCODES + 1)], st)
+                for c in range(1, NCODES + 1):
+                    if red[c]:
+                        st.pending_rc = 0
+                        raise ShkError(-c, "%s (on %d of the ranks)" % (ctx.L.shk_strerror(-c).decode(), red[c]))
+                st.ndistinct -= red[0]
+                st.nelts -= red[0]
+                out["removed"] += red[0]
         lo = hi + 1
     return out
 
 
-ROUTE_PIECE = 1 << 25   # elements per peer per exchange (256 MB of key words)
+# Elements per peer per collective call. One RCCL send/receive of 2 GiB or more arrives damaged on this stack: with
+# plain torch tensors and one rank, all_to_all / all_to_all_single of 2^28 int64 (2 GiB) deliver exactly half of the
+# words wrong, 2^27 words (1 GiB) are intact (tools/a2a_probe.py, profiles/r02_a2a_probe.json) -- a 32-bit byte count
+# somewhere below torch.distributed. Messages are therefore cut into pieces of at most 2^27 words (1 GiB) per peer.
+ROUTE_PIECE = 1 << 27
 
 
 class _CAI:
     """expose a raw device pointer to torch through __cuda_array_interface__"""
 
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
 def wrap_words(ptr, n, device):
@@ -198,38 +279,93 @@ def wrap_words(ptr, n, device):
     return torch.frombuffer((ctypes.c_int64 * n).from_address(ptr), dtype=torch.int64)
 
 
+def wrap_bytes(ptr, n, device):
+    if device.type == "cuda":
+        return torch.as_tensor(_CAI(ptr, n, "|u1"), device=device)
+    import ctypes
+    return torch.frombuffer((ctypes.c_uint8 * n).from_address(ptr), dtype=torch.uint8)
+
+
+class Exchange:
+    """one all-to-all of key words in flight: start() after shk_route_words, wait() before shk_stage_words. Between the
+    two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
+    behind compute: xGMI moves 8 B per routed key while the CUs hash."""
+
+    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True):
+        dp, sc = ctx.route_words(nwords, world)
+        self.send = wrap_words(dp, nwords, device)
+        self.world, self.device = world, device
+        # every rank learns every bin size in one all-gather: its own receive counts and the number of pieces
+        mine = torch.tensor(sc, dtype=torch.int64, device=device)
+        allc = torch.empty((world * world,), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allc, mine)
+        allc = allc.view(world, world).tolist()
+        rc = [allc[p][rank] for p in range(world)]
+        mx = max(max(row) for row in allc)
+        self.recv = torch.empty((sum(rc),), dtype=torch.int64, device=device)
+        soff = [sum(sc[:p]) for p in range(world)]
+        roff = [sum(rc[:p]) for p in range(world)]
+        self.work = []
+        if world == 1 and not os.environ.get("SHK_A2A_NO_BYPASS"):     # (the variable lets a one-rank test drive the collective)
+            self.recv.copy_(self.send)
+            return
+        piece_words = int(os.environ.get("SHK_ROUTE_PIECE", ROUTE_PIECE))
+        grouped = device.type == "cuda" and not os.environ.get("SHK_A2A_SINGLE")
+        for r0 in range(0, max(mx, 1), piece_words):
+            ins = [self.send[soff[p] + min(r0, sc[p]): soff[p] + min(r0 + piece_words, sc[p])] for p in range(world)]
+            outs = [self.recv[roff[p] + min(r0, rc[p]): roff[p] + min(r0 + piece_words, rc[p])] for p in range(world)]
+            if grouped:
+                # RCCL: grouped sends/receives straight between the bins and their places in `recv` (views, no staging)
+                w = dist.all_to_all(outs, ins, async_op=async_op)
+                if async_op:
+                    self.work.append(w)
+                continue
+            isz, osz = [int(x.numel()) for x in ins], [int(x.numel()) for x in outs]
+            piece = torch.empty((sum(osz),), dtype=torch.int64, device=device)
+            dist.all_to_all_single(piece, torch.cat(ins), output_split_sizes=osz, input_split_sizes=isz)
+            o = 0
+            for p in range(world):
+                outs[p].copy_(piece[o:o + osz[p]])
+                o += osz[p]
+
+    def wait(self):
+        """the received words, complete and visible to the library's stream"""
+        for w in self.work:
+            w.wait()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return self.recv
+
+
 def route_words(ctx, nwords, hb, world, rank, device):
     """Exchange the key words shk_hash_chunks left in the context (their chunk indices are already
     global: a sharded context labels chunk i as i * world + rank, so the ranks' parts interleave like
     the reference's file queue, cqf/CQF_mt.h:828-830): the library bins them by owner
-    (shk_route_words), and the bins travel in all-to-alls of at most ROUTE_PIECE words per peer (one
-    RCCL all_to_all_single of ~1.6 GB per peer was observed to deliver only its first 832 MB on this
-    stack; bounded pieces also bound the staging memory)."""
-    dp, sc = ctx.route_words(nwords, world)
-    send = wrap_words(dp, nwords, device)
-    send_counts = torch.tensor(sc, dtype=torch.int64, device=device)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts)
-    rc = recv_counts.tolist()
-    recv = torch.empty((sum(rc),), dtype=torch.int64, device=device)
-    mx = _allreduce([max(sc + rc)], device, dist.ReduceOp.MAX)[0]
-    soff = [sum(sc[:p]) for p in range(world)]
-    roff = [sum(rc[:p]) for p in range(world)]
-    for r0 in range(0, max(mx, 1), ROUTE_PIECE):
-        ins = [send[soff[p] + min(r0, sc[p]): soff[p] + min(r0 + ROUTE_PIECE, sc[p])] for p in range(world)]
-        outs = [recv[roff[p] + min(r0, rc[p]): roff[p] + min(r0 + ROUTE_PIECE, rc[p])] for p in range(world)]
-        if world == 1 and not os.environ.get("SHK_A2A_NO_BYPASS"):     # (the variable lets a one-rank test drive the collective)
-            outs[0].copy_(ins[0])
-            continue
-        if device.type == "cuda" and not os.environ.get("SHK_A2A_SINGLE"):
-            # RCCL: grouped sends/receives straight between the bins and their places in `recv` (views, no staging copies)
-            dist.all_to_all(outs, ins)
-            continue
-        isz, osz = [int(x.numel()) for x in ins], [int(x.numel()) for x in outs]
-        piece = torch.empty((sum(osz),), dtype=torch.int64, device=device)
-        dist.all_to_all_single(piece, torch.cat(ins), output_split_sizes=osz, input_split_sizes=isz)
-        o = 0
-        for p in range(world):
-            outs[p].copy_(piece[o:o + osz[p]])
-            o += osz[p]
-    return recv
+    (shk_route_words), one all-to-all moves the bins. Blocking form of `Exchange`."""
+    return Exchange(ctx, nwords, hb, world, rank, device, async_op=False).wait()
+
+
+def export_cqf(ctx, st, path, world, rank, device, qb, k=21):
+    """One .cqf of the whole filter from the ranks' shards: rank 0 gathers the shard tables (device to device over
+    RCCL / gloo), re-lays their runs into the single table on its GPU (shk_import_shards: clusters may now cross the
+    old shard borders) and writes header + blocks exactly as qf_serialize would. Returns the path on rank 0."""
+    from . import Context
+    ptr, nbytes = ctx.table_ptr()
+    mine = torch.empty((nbytes + 16,), dtype=torch.uint8, device=device)
+    mine[:nbytes].copy_(wrap_bytes(ptr, nbytes, device))
+    mine[nbytes:].zero_()
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    if world > 1:
+        dist.gather(mine, parts, dst=0)
+    else:
+        parts = [mine]
+    if rank != 0:
+        return None
+    full = Context(qb=qb, k=k, max_batch_keys=1 << 16, device=(device.index or 0) if device.type == "cuda" else 0,
+                   lib_path=getattr(ctx, "lib_path", None))
+    try:
+        full.import_shards_device([p.data_ptr() for p in parts], nbytes, st.nelts, st.ndistinct)
+        full.export_cqf(path)
+    finally:
+        full.close()
+    return path

@@ -24,7 +24,7 @@ def _data(rank):
     return fq, chunks_by_records(fq, 6)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, nd=ND, out_path=None):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "sh-assembly_amd"))
@@ -36,12 +36,27 @@ def _worker(rank, world, port, q):
     fq, (offs, lens) = _data(rank)
     ctx = shk.Context(qb=QB, k=K, min_denoise_len=ML, max_batch_bytes=1 << 20, max_batch_keys=1 << 16,
                       shard_index=rank, num_shards=world, threads_per_group=64, hash_groups=2, lib_path=EMU)
-    st = shkdist.ShardState(TRIG, ND, dev)
+    st = shkdist.ShardState(TRIG, nd, dev)
     hb = QB + 8
-    dp, nw = ctx.hash_chunks(fq, offs, lens)
-    recv = shkdist.route_words(ctx, nw, hb, world, rank, dev)
-    ctx.stage_words(recv.data_ptr(), recv.numel())
-    out = shkdist.sharded_count(ctx, st, len(offs) * world)
+    # two batches, the second one's exchange started before the first is staged (the pipelined form bench.py uses)
+    half = len(offs) // 2
+    out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
+    _, nw = ctx.hash_chunks(fq, offs[:half], lens[:half])
+    ex = shkdist.Exchange(ctx, nw, hb, world, rank, dev)
+    _, nw2 = ctx.hash_chunks(fq, offs[half:], lens[half:])
+    ex2 = shkdist.Exchange(ctx, nw2, hb, world, rank, dev)
+    allw = []
+    for e, n in ((ex, half), (ex2, len(offs) - half)):
+        recv = e.wait()
+        allw.append(recv.clone())
+        ctx.stage_words(recv.data_ptr(), recv.numel())
+        o = shkdist.sharded_count(ctx, st, n * world)
+        for kk in out:
+            out[kk] += o[kk]
+    shkdist.check(ctx, st)
+    recv = torch.cat(allw)
+    if out_path:
+        shkdist.export_cqf(ctx, st, out_path, world, rank, dev, QB, K)
     # (key, count) content of this shard through lookups of every key it received
     keys = sorted(set(int(x) & ((1 << hb) - 1) for x in recv.tolist()))
     cnt, _ = ctx.lookup(keys, mode=2)
@@ -51,16 +66,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_shards_match_single_filter():
+def _run(world, nd, out_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     import torch.multiprocessing as mp
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29600 + os.getpid() % 300
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() * 7 + world * 3 + nd) % 300
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, nd, out_path)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -68,11 +83,11 @@ def test_two_shards_match_single_filter():
     # oracle: one filter, chunks in the interleaved order rank0.c0, rank1.c0, rank0.c1, ...
     O = cqflibs.oracle()
     o = O.new(QB)
-    d = [_data(r) for r in range(2)]
+    d = [_data(r) for r in range(world)]
     nch = len(d[0][1][0])
-    left, rounds, removed = ND, 0, 0
+    left, rounds, removed = nd, 0, 0
     for j in range(nch):
-        for r in range(2):
+        for r in range(world):
             fq, (offs, lens) = d[r]
             o.reads_to_kmers(fq[offs[j]:offs[j] + lens[j]], K)
             if left and o.ndistinct() >= TRIG:
@@ -80,8 +95,15 @@ def test_two_shards_match_single_filter():
                 removed += o.denoise_round(ML)
                 rounds += 1
     assert not o.full()
+    return res, o, rounds
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shards_match_single_filter(world, tmp_path):
+    out_path = str(tmp_path / "stitched.cqf")
+    res, o, rounds = _run(world, ND, out_path)
     out0 = res[0][1]
-    assert res[0][1] == res[1][1]                       # every rank took the same decisions
+    assert all(r[1] == out0 for r in res)               # every rank took the same decisions
     assert out0["denoise_rounds"] == rounds and rounds >= 1
     merged = {}
     for _, _, _, _, kc, _ in res:
@@ -92,6 +114,28 @@ def test_two_shards_match_single_filter():
     # the range-end singletons of the deNoise walk, which restarts per shard
     assert {k: c for k, c in merged.items() if c >= 2} == {k: c for k, c in truth.items() if c >= 2}
     diff = set(k for k, c in merged.items() if c == 1) ^ set(k for k, c in truth.items() if c == 1)
-    assert len(diff) <= 2 * rounds * 2
-    assert abs(res[0][2] - o.ndistinct()) <= 2 * rounds * 2
+    assert len(diff) <= 2 * rounds * world
+    assert abs(res[0][2] - o.ndistinct()) <= 2 * rounds * world
     assert res[0][2] == sum(r[5] for r in res)           # global count = sum of the shards' counts
+    # the stitched .cqf rank 0 wrote (shk_import_shards on the gathered tables): holds exactly the shards' entries, in
+    # one canonical table, with the filter-wide counters in its header
+    f = cqflibs.oracle().load(out_path)
+    assert dict(f.dump()) == merged and f.check_offset()
+    assert (f.nelts(), f.ndistinct()) == (res[0][3], res[0][2])
+    canon = cqflibs.oracle().new(QB)
+    for k, c in sorted(merged.items()):
+        canon.insert(k, c)
+    assert f.blocks() == canon.blocks()
+    for x in (f, canon, o):
+        x.free()
+
+
+def test_stitched_export_equals_single_table_bytes(tmp_path):
+    """without deNoise rounds nothing depends on the shards' walks: the stitched file is the single-filter .cqf, byte for byte"""
+    out_path = str(tmp_path / "stitched.cqf")
+    res, o, rounds = _run(2, 0, out_path)
+    assert rounds == 0
+    single = str(tmp_path / "single.cqf")
+    o.serialize(single)
+    assert open(out_path, "rb").read() == open(single, "rb").read()
+    o.free()
