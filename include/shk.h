@@ -20,8 +20,10 @@
  *                         unitig (Contiger, first slice)                   src/contig_assembly.cpp:3028-3218
  *   shk_unitigs_from_seeds its two calls per seed + median abundance        src/contig_assembly.cpp:1886-1904; base/Utility.cpp:27-40
  *   shk_select_seeds      processDataChunk's seed rule                     src/contig_assembly.cpp:1856-1876
- *   shk_find_unitigs      find_unitigs: seeds + work queue of branch
- *                         neighbours + duplicate removal + writer (set-level) src/contig_assembly.cpp:3122-3160, 935-954, 606-626
+ *   shk_find_unitigs,     find_unitigs_mt_master/worker: seeds walked both ways, work queue of branch neighbours,
+ *   shk_unitigs_add_*,    startKmer2unitig with "smaller id wins", known-node stops, pure circles; check_unitig,
+ *   shk_unitig_set_write  track_kmer_worker, build_graph_worker, writer -- all on the device (csrc/unitig_kernels.hip)
+ *                                                                         src/contig_assembly.cpp:2034-2269, 3018-3218, 935-1084, 600-629
  *   shk_insert_counted    qf_insert_advance(count > 1) -> insert_advance    cqf/gqf.c:2024-2136 (local-QF flush, CQF_mt.h:588-607)
  *   shk_dump              qf_iterator / qfi_get / qfi_next / qfi_end        cqf/gqf.c:2474-2601
  *   shk_merge             qf_merge                                          cqf/gqf.c:2614-2655
@@ -256,7 +258,7 @@ int shk_unitigs_from_seeds(shk_ctx *ctx, const char *seeds, const uint32_t *seed
  * thread schedule's and are not reproduced. */
 typedef struct shk_unitig_stats {
   uint64_t unitigs, total_len;   /* kept unitigs and their summed length */
-  uint64_t rounds, extensions;   /* batched rounds; single forward extensions run on the device */
+  uint64_t rounds, extensions;   /* launches of the walk kernel; bases appended by all walks (duplicates included) */
   uint64_t duplicates, truncated;/* unitigs found again and dropped; walks cut at max_len */
 } shk_unitig_stats;
 int shk_find_unitigs(shk_ctx *ctx, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
@@ -271,6 +273,12 @@ void shk_unitig_set_free(shk_unitig_set *u);
 int shk_unitigs_add_seeds(shk_ctx *ctx, shk_unitig_set *u, const char *seeds, const uint32_t *seed_counts, uint32_t n,
                           uint32_t k, uint64_t abundance_min, uint32_t max_len, int mark_traveled);
 int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *out_path, shk_unitig_stats *stats);
+/* The command line's inner loop without the seeds leaving the device: the seeds of the reads in the given FASTQ chunks
+ * (rule of shk_select_seeds with use_traveled = 1) become contigs and are walked at once, every lookup marking the
+ * traveled bit as the reference's does. *nseeds (may be NULL) = seeds taken from this batch. */
+int shk_unitigs_add_reads(shk_ctx *ctx, shk_unitig_set *u, const void *text, int text_on_device, uint64_t text_bytes,
+                          const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks, uint32_t k,
+                          uint64_t abundance_min, uint64_t count_min, uint64_t count_max, uint32_t max_len, uint64_t *nseeds);
 /* Seeds of the reads in the given FASTQ chunks (processDataChunk, contig_assembly.cpp:1856-1876): the k-mer at
  * len/2 - k/2 of every read, upper-cased, without 'N', whose filter count lies in [count_min, count_max]; with
  * use_traveled != 0 the lookup marks the k-mer and a k-mer that was already marked gives no seed. out_seeds

@@ -20,6 +20,7 @@
 #include "cqf_kernels.hip"
 #include "merge2_kernels.hip"
 #include "walk_kernels.hip"
+#include "unitig_kernels.hip"
 
 #define SHK_SLACK 256  // bytes of slack behind buffers read with wide loads
 
@@ -1556,169 +1557,306 @@ extern "C" int shk_unitigs_from_seeds(shk_ctx *c, const char *seeds, const uint3
   return SHK_OK;
 }
 
-static std::string walk_rc(const std::string &s) {
-  std::string r(s.rbegin(), s.rend());
-  for (auto &ch : r) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
-  return r;
+// ------------------------------------------------------------------ Contiger: the unitig set on the device
+// (unitig_kernels.hip; the reference's find_unitigs_mt_master/worker, check_unitig, track_kmer_worker,
+// build_graph_worker and the writer, src/contig_assembly.cpp:2034-2269, 935-1084, 600-629)
+template <typename T> static int ug_grow(T **p, uint64_t old_n, uint64_t new_n, hipStream_t st, bool zero_new) {
+  T *q = nullptr;
+  if (dmalloc(&q, new_n)) return SHK_ERR_HIP;
+  if (zero_new) HIPCHK(hipMemsetAsync(q, 0, new_n * sizeof(T), st));
+  if (*p && old_n) HIPCHK(hipMemcpyAsync(q, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, st));
+  if (*p) { HIPCHK(hipStreamSynchronize(st)); hipFree(*p); }
+  *p = q;
+  return SHK_OK;
 }
 
-// All unitigs reachable from the seeds: the closure Contiger computes with its work queue
-// (contig_assembly.cpp:3122-3160: every solid neighbour met at a branch becomes a new contig that is
-// extended forward; :3018-3025, :935-954: a unitig found twice is kept once), as rounds of batched
-// extensions. The reference's result is the same SET of sequences (up to reverse complement and to where a
-// pure circle is cut); ids, order and orientation depend on its thread schedule and are not
-// reproduced. FASTA records as the reference writes them (:606-626) minus the L: links of the graph pass.
 struct shk_unitig_set {
-  struct Unit { std::string seq; int med; };
-  std::vector<Unit> units;
-  std::unordered_set<std::string> ends;     // first k-mer and RC(last k-mer) of every kept unitig (startKmer2unitig)
-  std::unordered_set<std::string> queued;   // start k-mers that were handed to a walk
+  shk_ctx *c = nullptr;
+  ShkUG G;
+  uint32_t cap = 0, mcap = 0, ccap = 0, lcap = 0;     // contigs, map slots, circle slots, list entries
+  uint32_t *d_list[2] = {nullptr, nullptr};
+  uint32_t *d_scal = nullptr;                          // [0] ncontigs [1] next_n [2] flags [3] nactive (seeds from reads)
+  unsigned long long *d_stats = nullptr;
+  uint32_t *h_scal = nullptr;                          // pinned mirror (4 u32 + 4 u64)
+  char *d_seeds = nullptr; uint32_t *d_counts = nullptr; uint64_t seeds_cap = 0;
+  uint32_t ncontigs = 1;                               // next free id (the reference starts with contigs.resize(1))
+  uint32_t k = 0, max_len = 0;
+  uint64_t amin = 0;
   shk_unitig_stats st;
-  shk_unitig_set() { memset(&st, 0, sizeof(st)); }
+  shk_unitig_set() { memset(&st, 0, sizeof(st)); memset(&G, 0, sizeof(G)); }
 };
 extern "C" shk_unitig_set *shk_unitig_set_new(void) { return new shk_unitig_set(); }
-extern "C" void shk_unitig_set_free(shk_unitig_set *u) { delete u; }
+extern "C" void shk_unitig_set_free(shk_unitig_set *u) {
+  if (!u) return;
+  if (u->c) {
+    hipSetDevice(u->c->dev);
+    hipStreamSynchronize(u->c->stream);
+    ShkUG &G = u->G;
+    hipFree(G.first_lo); hipFree(G.first_hi); hipFree(G.cur_lo); hipFree(G.cur_hi); hipFree(G.rc_lo); hipFree(G.rc_hi);
+    hipFree(G.fh); hipFree(G.rh); hipFree(G.hmin); hipFree(G.len); hipFree(G.l1); hipFree(G.cnt0); hipFree(G.state); hipFree(G.kind);
+    hipFree(G.stop); hipFree(G.mk_lo); hipFree(G.mk_hi); hipFree(G.mv); hipFree(G.ck); hipFree(G.cv);
+    hipFree(u->d_list[0]); hipFree(u->d_list[1]); hipFree(u->d_scal); hipFree(u->d_stats); hipFree(u->d_seeds); hipFree(u->d_counts);
+    if (u->h_scal) hipHostFree(u->h_scal);
+  }
+  delete u;
+}
+
+// capacities for `ncontigs_after` contig ids and `nlist` list entries
+static int ug_reserve(shk_unitig_set *u, uint64_t ncontigs_after, uint64_t nlist) {
+  shk_ctx *c = u->c;
+  ShkUG &G = u->G;
+  if (ncontigs_after + 1 > u->cap) {
+    uint64_t nc = u->cap ? u->cap : 1024;
+    while (nc < ncontigs_after + 1) nc *= 2;
+    if (nc > 0x7FFFFFF0ull) return SHK_ERR_BATCH;
+    const uint64_t o = u->cap;
+    if (ug_grow(&G.first_lo, o, nc, c->stream, false) || ug_grow(&G.first_hi, o, nc, c->stream, false) || ug_grow(&G.cur_lo, o, nc, c->stream, false) ||
+        ug_grow(&G.cur_hi, o, nc, c->stream, false) || ug_grow(&G.rc_lo, o, nc, c->stream, false) || ug_grow(&G.rc_hi, o, nc, c->stream, false) ||
+        ug_grow(&G.fh, o, nc, c->stream, false) || ug_grow(&G.rh, o, nc, c->stream, false) || ug_grow(&G.hmin, o, nc, c->stream, false) ||
+        ug_grow(&G.len, o, nc, c->stream, true) || ug_grow(&G.l1, o, nc, c->stream, true) || ug_grow(&G.cnt0, o, nc, c->stream, true) ||
+        ug_grow(&G.state, o, nc, c->stream, true) || ug_grow(&G.kind, o, nc, c->stream, true) || ug_grow(&G.stop, o, nc, c->stream, true))
+      return SHK_ERR_HIP;
+    u->cap = (uint32_t)nc; G.cap = (uint32_t)nc;
+  }
+  if (nlist > u->lcap) {
+    uint64_t nl = u->lcap ? u->lcap : 1024;
+    while (nl < nlist) nl *= 2;
+    if (ug_grow(&u->d_list[0], u->lcap, nl, c->stream, false) || ug_grow(&u->d_list[1], u->lcap, nl, c->stream, false)) return SHK_ERR_HIP;
+    u->lcap = (uint32_t)nl;
+  }
+  // every contig owns at most two keys; the table stays at most a quarter full
+  if (ncontigs_after * 8 > u->mcap) {
+    uint64_t nm = u->mcap ? u->mcap : 4096;
+    while (nm < ncontigs_after * 8) nm *= 2;
+    if (nm > 0x80000000ull) return SHK_ERR_BATCH;
+    uint64_t *ok_lo = G.mk_lo, *ok_hi = G.mk_hi; uint32_t *ov = G.mv;
+    const uint32_t ocap = u->mcap;
+    G.mk_lo = G.mk_hi = nullptr; G.mv = nullptr;
+    if (dmalloc(&G.mk_lo, nm) || dmalloc(&G.mk_hi, nm) || dmalloc(&G.mv, nm)) return SHK_ERR_HIP;
+    HIPCHK(hipMemsetAsync(G.mv, 0, nm * 4, c->stream));
+    G.mmask = (uint32_t)(nm - 1); u->mcap = (uint32_t)nm;
+    if (ocap) {
+      hipLaunchKernelGGL(k_ug_rehash, dim3((ocap + 255) / 256), dim3(256), 0, c->stream, G, (const uint64_t *)ok_lo, (const uint64_t *)ok_hi, (const uint32_t *)ov, ocap);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      hipFree(ok_lo); hipFree(ok_hi); hipFree(ov);
+    }
+  }
+  if (!u->ccap) {
+    const uint64_t ncs = 1 << 16;
+    if (dmalloc(&G.ck, ncs) || dmalloc(&G.cv, ncs)) return SHK_ERR_HIP;
+    HIPCHK(hipMemsetAsync(G.cv, 0, ncs * 4, c->stream));
+    G.cmask = (uint32_t)(ncs - 1); u->ccap = (uint32_t)ncs;
+  }
+  return SHK_OK;
+}
+
+static int ug_bind(shk_unitig_set *u, shk_ctx *c, uint32_t k, uint64_t amin, uint32_t max_len) {
+  if (u->c) {
+    if (u->c != c || u->k != k || u->amin != amin || u->max_len != max_len) return SHK_ERR_ARG;   // one filter, one set of rules
+    return SHK_OK;
+  }
+  u->c = c; u->k = k; u->amin = amin; u->max_len = max_len;
+  if (dmalloc(&u->d_scal, 16) || dmalloc(&u->d_stats, 8)) return SHK_ERR_HIP;
+  HIPCHK(hipHostMalloc((void **)&u->h_scal, 64, hipHostMallocDefault));
+  HIPCHK(hipMemsetAsync(u->d_scal, 0, 16 * 4, c->stream));
+  HIPCHK(hipMemsetAsync(u->d_stats, 0, 8 * 8, c->stream));
+  u->G.ncontigs = u->d_scal; u->G.next_n = u->d_scal + 1; u->G.flags = u->d_scal + 2; u->G.stats = u->d_stats;
+  return ug_reserve(u, 1024, 1024);
+}
+
+// rounds of k_ug_walk until no contig is open; d_list[0] holds `nactive` ids
+static int ug_run(shk_unitig_set *u, uint32_t nactive, int mark) {
+  shk_ctx *c = u->c;
+  uint32_t step = 2048;
+  if (const char *e = getenv("SHK_WALK_STEP")) { int v = atoi(e); if (v > 0) step = (uint32_t)v; }   // tests: force continuations
+  int cur = 0;
+  while (nactive) {
+    // a contig may queue up to 7 neighbours; every open contig may come back once
+    int rc = ug_reserve(u, (uint64_t)u->ncontigs + 8ull * nactive + 16, 8ull * nactive + 16);
+    if (rc) return rc;
+    u->h_scal[0] = u->ncontigs; u->h_scal[1] = 0; u->h_scal[2] = 0;
+    HIPCHK(hipMemcpyAsync(u->d_scal, u->h_scal, 12, hipMemcpyHostToDevice, c->stream));
+    u->G.next = u->d_list[cur ^ 1];
+    { ProfScope ps(c, KP_WALK);
+      hipLaunchKernelGGL(k_ug_walk, dim3((nactive + 63) / 64), dim3(64), 0, c->stream, u->G, (const uint32_t *)u->d_list[cur], nactive, c->tab[c->cur], c->q_lo,
+                         c->nslots, c->cfg.hb, u->k, u->amin, mark ? 1 : 2, step, u->max_len); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(u->h_scal, u->d_scal, 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (u->h_scal[2]) return u->h_scal[2] & SHK_UG_E_MAP ? SHK_ERR_CORRUPT : SHK_ERR_BATCH;
+    u->ncontigs = u->h_scal[0];
+    nactive = u->h_scal[1];
+    cur ^= 1;
+    u->st.rounds++;
+  }
+  // (the lists may have been swapped an odd number of times: nothing depends on which one is list 0 between calls)
+  return SHK_OK;
+}
 
 extern "C" int shk_unitigs_add_seeds(shk_ctx *c, shk_unitig_set *u, const char *seeds, const uint32_t *seed_counts, uint32_t n,
                                      uint32_t k, uint64_t abundance_min, uint32_t max_len, int mark_traveled) {
   if (!c || !u || (n && (!seeds || !seed_counts))) return SHK_ERR_ARG;
   if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
-  // A launch extends every open end by at most `step` bases (bounded result buffers); ends that fill their
-  // buffer simply continue in the next launch. At most `mmax` ends per launch.
-  uint32_t step = max_len - k < 2048 ? max_len - k : 2048;
-  if (const char *e = getenv("SHK_WALK_STEP")) { int v = atoi(e); if (v > 0 && (uint32_t)v < step) step = (uint32_t)v; }   // tests: force continuations
-  const uint32_t mmax = (uint32_t)((1ull << 30) / ((uint64_t)step * 5)) + 1;
-  shk_unitig_stats &st_ = u->st;
-  // work items: contig so far, its median, passes (2 for seeds: forward, RC, forward; 1 for branch neighbours)
-  struct Item { std::string seq; int med; int passes; std::vector<int> ab; bool open; };
-  std::vector<Item> work;
-  for (uint32_t i = 0; i < n; i++) {
-    std::string s(seeds + (size_t)i * k, k);
-    if (u->ends.count(s) || !u->queued.insert(s).second) continue;
-    work.push_back({s, (int)seed_counts[i], 2, {}, false});
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ug_bind(u, c, k, abundance_min, max_len);
+  if (rc || n == 0) return rc;
+  if ((uint64_t)n > u->seeds_cap) {
+    hipFree(u->d_seeds); hipFree(u->d_counts); u->d_seeds = nullptr; u->d_counts = nullptr;
+    if (dmalloc(&u->d_seeds, (uint64_t)n * k) || dmalloc(&u->d_counts, (uint64_t)n)) return SHK_ERR_HIP;
+    u->seeds_cap = n;
   }
-  std::vector<char> cur, first, ext;
-  std::vector<uint32_t> cnt, en, ncount;
-  std::vector<uint8_t> stp, br;
-  while (!work.empty()) {
-    st_.rounds++;
-    std::vector<Item> next;
-    for (int pass = 0; pass < 2; pass++) {
-      std::vector<uint32_t> open;
-      for (uint32_t i = 0; i < work.size(); i++)
-        if (work[i].passes == 2 || pass == 0) {
-          Item &it = work[i];
-          if (pass == 1) it.seq = walk_rc(it.seq);
-          // abundances start as (length - K + 1) copies of the contig's current median (contig_assembly.cpp:3049)
-          it.ab.assign(it.seq.size() - k + 1, it.med);
-          it.open = true;
-          open.push_back(i);
-        }
-      while (!open.empty()) {
-        const uint32_t m = open.size() < mmax ? (uint32_t)open.size() : mmax;
-        cur.resize((size_t)m * k); first.resize((size_t)m * k); ext.resize((size_t)m * step);
-        cnt.resize((size_t)m * step); en.resize(m); stp.resize(m); br.resize(m); ncount.resize((size_t)m * 8);
-        for (uint32_t j = 0; j < m; j++) {
-          Item &it = work[open[j]];
-          memcpy(&first[(size_t)j * k], it.seq.data(), k);
-          memcpy(&cur[(size_t)j * k], it.seq.data() + it.seq.size() - k, k);
-        }
-        int rc = shk_extend_forward(c, cur.data(), first.data(), m, k, abundance_min, mark_traveled, step, ext.data(), cnt.data(),
-                                    en.data(), stp.data(), br.data(), ncount.data());
-        if (rc) return rc;
-        st_.extensions += m;
-        std::vector<uint32_t> still(open.begin() + m, open.end());
-        for (uint32_t j = 0; j < m; j++) {
-          Item &it = work[open[j]];
-          uint32_t take = en[j];
-          bool cut = false;
-          if (it.seq.size() + take >= max_len) { take = max_len - (uint32_t)it.seq.size(); cut = stp[j] == SHK_STOP_BUFFER || take < en[j]; }
-          for (uint32_t t = 0; t < take; t++) it.ab.push_back((int)cnt[(size_t)j * step + t]);
-          it.seq.append(&ext[(size_t)j * step], take);
-          if (stp[j] == SHK_STOP_BUFFER && !cut) { still.push_back(open[j]); continue; }   // goes on in the next launch
-          if (cut) st_.truncated++;
-          it.open = false;
-          it.med = walk_median(it.ab);
-          it.ab.clear(); it.ab.shrink_to_fit();
-          if (stp[j] == SHK_STOP_BRANCH && !cut) {
-            // solid neighbours of the last k-mer start new contigs (contig_assembly.cpp:3133-3160)
-            const std::string last = it.seq.substr(it.seq.size() - k);
-            for (int x = 0; x < 4; x++)
-              if (br[j] & (1u << x)) {
-                std::string s2 = last.substr(1) + "ACGT"[x];
-                if (!u->ends.count(s2) && u->queued.insert(s2).second) next.push_back({s2, (int)ncount[(size_t)j * 8 + x], 1, {}, false});
-              }
-            for (int z = 0; z < 4; z++)
-              if (br[j] & (16u << z)) {
-                std::string s2 = walk_rc(std::string(1, "ACGT"[z]) + last.substr(1));
-                if (!u->ends.count(s2) && u->queued.insert(s2).second) next.push_back({s2, (int)ncount[(size_t)j * 8 + 4 + z], 1, {}, false});
-              }
-          }
-        }
-        open.swap(still);
-      }
-    }
-    // keep every unitig once: its first k-mer and the RC of its last k-mer identify it in either orientation
-    for (auto &it : work) {
-      const std::string f = it.seq.substr(0, k), e = walk_rc(it.seq.substr(it.seq.size() - k));
-      if (u->ends.count(f) || u->ends.count(e)) { st_.duplicates++; continue; }
-      u->ends.insert(f); u->ends.insert(e);
-      u->units.push_back({it.seq, it.med});
-    }
-    work.clear();
-    for (auto &it : next)
-      if (!u->ends.count(it.seq)) work.push_back(it);
+  rc = ug_reserve(u, (uint64_t)u->ncontigs + n + 16, (uint64_t)n + 16);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(u->d_seeds, seeds, (size_t)n * k, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(u->d_counts, seed_counts, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_ug_add_seeds, dim3((n + 255) / 256), dim3(256), 0, c->stream, u->G, (const char *)u->d_seeds, (const uint32_t *)u->d_counts, n, k,
+                     u->ncontigs, u->d_list[0]);
+  HIPCHK(hipGetLastError());
+  u->ncontigs += n;
+  rc = ug_run(u, n, mark_traveled);
+  return finish(c, rc);
+}
+
+// Seeds straight from FASTQ chunks (processDataChunk's rule, contig_assembly.cpp:1856-1876) and their walks, without
+// the seeds leaving the device: parse -> k_select_seeds (lookup that marks) -> new contigs -> rounds.
+extern "C" int shk_unitigs_add_reads(shk_ctx *c, shk_unitig_set *u, const void *text, int text_on_device, uint64_t text_bytes,
+                                     const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks, uint32_t k,
+                                     uint64_t abundance_min, uint64_t count_min, uint64_t count_max, uint32_t max_len,
+                                     uint64_t *nseeds) {
+  if (!c || !u || !text || !chunk_off || !chunk_len || nchunks == 0 || nchunks > SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (k < 2 || k > SHK_WALK_MAX_K || max_len < k + 1) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  int rc = ug_bind(u, c, k, abundance_min, max_len);
+  if (rc) return rc;
+  const uint8_t *dtext;
+  uint64_t nreads;
+  rc = parse_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads);
+  if (rc) return finish(c, rc);
+  if (nseeds) *nseeds = 0;
+  if (nreads == 0) return finish(c, 0);
+  if (nreads > 0x7FFFFFF0ull) return SHK_ERR_BATCH;
+  if (nreads > u->seeds_cap) {
+    hipFree(u->d_seeds); hipFree(u->d_counts); u->d_seeds = nullptr; u->d_counts = nullptr;
+    if (dmalloc(&u->d_seeds, nreads * k) || dmalloc(&u->d_counts, nreads)) return SHK_ERR_HIP;
+    u->seeds_cap = nreads;
   }
-  return SHK_OK;
+  rc = ug_reserve(u, (uint64_t)u->ncontigs + nreads + 16, nreads + 16);
+  if (rc) return rc;
+  { ProfScope ps(c, KP_WALK);
+    hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
+                       c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, nreads, k, count_min, count_max, 1, u->d_seeds, u->d_counts); }
+  u->h_scal[0] = u->ncontigs; u->h_scal[1] = 0; u->h_scal[2] = 0; u->h_scal[3] = 0;
+  HIPCHK(hipMemcpyAsync(u->d_scal, u->h_scal, 16, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_ug_seeds_from_reads, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, u->G, (const char *)u->d_seeds,
+                     (const uint32_t *)u->d_counts, nreads, k, u->d_list[0], u->d_scal + 3);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(u->h_scal, u->d_scal, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (u->h_scal[2]) return finish(c, SHK_ERR_BATCH);
+  u->ncontigs = u->h_scal[0];
+  const uint32_t n = u->h_scal[3];
+  if (nseeds) *nseeds = n;
+  rc = ug_run(u, n, 1);
+  return finish(c, rc);
 }
 
 extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *out_path, shk_unitig_stats *stats) {
   if (!u || !out_path) return SHK_ERR_ARG;
   FILE *fo = fopen(out_path, "w");
   if (!fo) return SHK_ERR_IO;
-  // final numbering and the start-k-mer map of the graph pass (track_kmer_worker, contig_assembly.cpp:956-1010):
-  // first k-mer -> +id, RC(last k-mer) -> -id (ids from 1; a unitig whose two keys coincide keeps +id)
-  std::unordered_map<std::string, long long> start;
-  start.reserve(u->units.size() * 2);
-  for (size_t i = 0; i < u->units.size(); i++) {
-    const std::string &sq = u->units[i].seq;
-    const std::string f = sq.substr(0, k), e = walk_rc(sq.substr(sq.size() - k));
-    if (f != e) start[e] = -(long long)(i + 1);
-    start[f] = (long long)(i + 1);
+  if (!u->c) {          // nothing was ever added
+    fclose(fo);
+    if (stats) *stats = u->st;
+    return SHK_OK;
   }
-  u->st.total_len = 0;
-  for (size_t i = 0; i < u->units.size(); i++) {
-    const std::string &sq = u->units[i].seq;
-    const long long len = (long long)sq.size();
-    fprintf(fo, ">%zu LN:i:%lld KC:i:%lld km:f:%d", i, len, (long long)u->units[i].med * (len - (long long)k + 1), u->units[i].med);
-    // build_graph_worker (:1012-1084) + writer (:611-624): successors in A,C,G,T order, predecessors in T,G,C,A order
-    std::string fix = sq.substr(sq.size() - k + 1);
-    for (int x = 0; x < 4; x++) {
-      auto it = start.find(fix + "ACGT"[x]);
-      if (it == start.end()) continue;
-      if (it->second > 0) fprintf(fo, " L:+:%lld:+", it->second - 1); else fprintf(fo, " L:+:%lld:-", -it->second - 1);
+  if (k != u->k) { fclose(fo); return SHK_ERR_ARG; }
+  shk_ctx *c = u->c;
+  HIPCHK(hipSetDevice(c->dev));
+  const uint32_t n = u->ncontigs;
+  uint32_t *d_keep = nullptr, *d_lens = nullptr, *d_ulen = nullptr, *d_ul1 = nullptr, *d_cnt = nullptr;
+  uint64_t *d_newid = nullptr, *d_off = nullptr, *d_uoff = nullptr;
+  char *d_bases = nullptr;
+  int32_t *d_med = nullptr, *d_links = nullptr;
+  uint64_t *m_lo = nullptr, *m_hi = nullptr; uint32_t *m_v = nullptr;
+  int rc = SHK_OK;
+  std::vector<char> bases;
+  std::vector<uint64_t> uoff;
+  std::vector<uint32_t> ulen;
+  std::vector<int32_t> med, links;
+  uint64_t nunits = 0, total = 0;
+  do {
+    if ((uint64_t)n / SHK_SCAN_TILE + 2 > 8192) { rc = SHK_ERR_BATCH; break; }     // run_scan's scratch in the context
+    if (dmalloc(&d_keep, (uint64_t)n + 1) || dmalloc(&d_lens, (uint64_t)n + 1) || dmalloc(&d_newid, (uint64_t)n + 2) || dmalloc(&d_off, (uint64_t)n + 2)) { rc = SHK_ERR_HIP; break; }
+    hipLaunchKernelGGL(k_ug_check, dim3((n + 255) / 256), dim3(256), 0, c->stream, u->G, n, d_keep, d_lens);
+    if (run_scan<uint32_t>(c, d_keep, n, nullptr, d_newid) || run_scan<uint32_t>(c, d_lens, n, nullptr, d_off)) { rc = SHK_ERR_HIP; break; }
+    if (hipMemcpyAsync(c->h_pinned + 45, d_newid + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->h_pinned + 46, d_off + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
+    nunits = c->h_pinned[45]; total = c->h_pinned[46];
+    if (nunits == 0) break;
+    if (dmalloc(&d_bases, total + 16) || dmalloc(&d_cnt, total + 16) || dmalloc(&d_uoff, nunits + 1) || dmalloc(&d_ulen, nunits + 1) ||
+        dmalloc(&d_ul1, nunits + 1) || dmalloc(&d_med, nunits + 1) || dmalloc(&d_links, nunits * 8 + 8)) { rc = SHK_ERR_HIP; break; }
+    { ProfScope ps(c, KP_WALK);
+      hipLaunchKernelGGL(k_ug_emit, dim3((n + 63) / 64), dim3(64), 0, c->stream, u->G, n, (const uint32_t *)d_keep, (const uint64_t *)d_newid, (const uint64_t *)d_off,
+                         c->tab[c->cur], c->q_lo, c->nslots, c->cfg.hb, k, u->amin, d_bases, d_cnt, d_uoff, d_ulen, d_ul1); }
+    hipLaunchKernelGGL(k_ug_median, dim3((uint32_t)nunits), dim3(SHK_WAVE), 0, c->stream, (uint32_t)nunits, (const uint64_t *)d_uoff, (const uint32_t *)d_ulen,
+                       (const uint32_t *)d_ul1, (const uint32_t *)d_cnt, k, d_med);
+    // the graph pass's own map: first k-mer -> +number, RC(last k-mer) -> -number
+    uint64_t nm = 4096;
+    while (nm < nunits * 8) nm *= 2;
+    if (dmalloc(&m_lo, nm) || dmalloc(&m_hi, nm) || dmalloc(&m_v, nm)) { rc = SHK_ERR_HIP; break; }
+    if (hipMemsetAsync(m_v, 0, nm * 4, c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
+    ShkUG G2 = u->G;
+    G2.mk_lo = m_lo; G2.mk_hi = m_hi; G2.mv = m_v; G2.mmask = (uint32_t)(nm - 1);
+    hipLaunchKernelGGL(k_ug_map2, dim3((n + 255) / 256), dim3(256), 0, c->stream, G2, n, (const uint32_t *)d_keep, (const uint64_t *)d_newid);
+    hipLaunchKernelGGL(k_ug_links, dim3((n + 255) / 256), dim3(256), 0, c->stream, G2, n, (const uint32_t *)d_keep, (const uint64_t *)d_newid, k, d_links);
+    if (hipGetLastError() != hipSuccess) { rc = SHK_ERR_HIP; break; }
+    bases.resize(total); uoff.resize(nunits); ulen.resize(nunits); med.resize(nunits); links.resize(nunits * 8);
+    if (hipMemcpyAsync(bases.data(), d_bases, total, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(uoff.data(), d_uoff, nunits * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(ulen.data(), d_ulen, nunits * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(med.data(), d_med, nunits * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(links.data(), d_links, nunits * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(u->h_scal + 4, u->d_stats, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
+  } while (0);
+  hipStreamSynchronize(c->stream);
+  hipFree(d_keep); hipFree(d_lens); hipFree(d_newid); hipFree(d_off); hipFree(d_bases); hipFree(d_cnt); hipFree(d_uoff); hipFree(d_ulen);
+  hipFree(d_ul1); hipFree(d_med); hipFree(d_links); hipFree(m_lo); hipFree(m_hi); hipFree(m_v);
+  if (rc) { fclose(fo); return finish(c, rc); }
+  // the records as the reference writes them (:606-626): ids 0-based in final numbering, successors then predecessors
+  std::string line;
+  for (uint64_t i = 0; i < nunits; i++) {
+    const long long len = ulen[i];
+    char head[160];
+    int hn = snprintf(head, sizeof(head), ">%llu LN:i:%lld KC:i:%lld km:f:%d", (unsigned long long)i, len, (long long)med[i] * (len - (long long)k + 1), med[i]);
+    line.assign(head, (size_t)hn);
+    for (int x = 0; x < 8; x++) {
+      const int32_t v = links[i * 8 + x];
+      if (!v) continue;
+      hn = snprintf(head, sizeof(head), " L:%c:%d:%c", x < 4 ? '+' : '-', (v > 0 ? v : -v) - 1, v > 0 ? '+' : '-');
+      line.append(head, (size_t)hn);
     }
-    fix = walk_rc(sq.substr(0, k - 1));
-    for (int x = 3; x >= 0; x--) {
-      auto it = start.find(fix + "ACGT"[x]);
-      if (it == start.end()) continue;
-      if (it->second > 0) fprintf(fo, " L:-:%lld:+", it->second - 1); else fprintf(fo, " L:-:%lld:-", -it->second - 1);
-    }
-    fprintf(fo, "\n%s\n", sq.c_str());
-    u->st.total_len += (uint64_t)len;
+    line.push_back('\n');
+    line.append(bases.data() + uoff[i], (size_t)len);
+    line.push_back('\n');
+    fwrite(line.data(), 1, line.size(), fo);
   }
   fclose(fo);
-  u->st.unitigs = u->units.size();
+  const unsigned long long *ds = reinterpret_cast<const unsigned long long *>(u->h_scal + 4);
+  u->st.unitigs = nunits; u->st.total_len = total;
+  if (nunits) { u->st.extensions = ds[0]; u->st.duplicates = ds[1]; u->st.truncated = ds[2]; }
   if (stats) *stats = u->st;
-  return SHK_OK;
+  return finish(c, SHK_OK);
 }
 
 extern "C" int shk_find_unitigs(shk_ctx *c, const char *seeds, const uint32_t *seed_counts, uint32_t n, uint32_t k,
                                 uint64_t abundance_min, uint32_t max_len, const char *out_path, shk_unitig_stats *stats) {
   if (!out_path) return SHK_ERR_ARG;
-  shk_unitig_set u;
-  int rc = shk_unitigs_add_seeds(c, &u, seeds, seed_counts, n, k, abundance_min, max_len, 0);
-  if (!rc) rc = shk_unitig_set_write(&u, k, out_path, stats);
+  shk_unitig_set *u = shk_unitig_set_new();
+  int rc = shk_unitigs_add_seeds(c, u, seeds, seed_counts, n, k, abundance_min, max_len, 0);
+  if (!rc) rc = shk_unitig_set_write(u, k, out_path, stats);
+  shk_unitig_set_free(u);
   return rc;
 }
 

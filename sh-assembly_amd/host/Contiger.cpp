@@ -112,17 +112,13 @@ int main(int argc, char *argv[]) {
   shk_unitig_set *set = shk_unitig_set_new();
   vector<char> text;
   vector<uint64_t> off, len;
-  vector<char> seeds;
-  vector<uint32_t> counts;
   uint64_t nseeds_total = 0;
   auto flush = [&]() -> int {
     if (off.empty()) return 0;
-    const uint32_t cap = (uint32_t)(text.size() / 4 + 16);     // more than one seed per 4-line record is impossible
-    seeds.resize((size_t)cap * K); counts.resize(cap);
-    uint32_t n = 0;
-    int r = shk_select_seeds(ctx, text.data(), 0, text.size(), off.data(), len.data(), (uint32_t)off.size(), (uint32_t)K, (uint64_t)xmin,
-                             (uint64_t)xmax, 1, seeds.data(), counts.data(), cap, &n);
-    if (!r && n) r = shk_unitigs_add_seeds(ctx, set, seeds.data(), counts.data(), n, (uint32_t)K, (uint64_t)amin, (uint32_t)max_len, 1);
+    uint64_t n = 0;
+    // seeds of this batch of parts (processDataChunk's rule) and their walks, all on the device
+    int r = shk_unitigs_add_reads(ctx, set, text.data(), 0, text.size(), off.data(), len.data(), (uint32_t)off.size(), (uint32_t)K,
+                                  (uint64_t)amin, (uint64_t)xmin, (uint64_t)xmax, (uint32_t)max_len, &n);
     nseeds_total += n;
     text.clear(); off.clear(); len.clear();
     return r;

@@ -63,7 +63,7 @@ EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
-           "shk_last_error_bits", "shk_insert_counted", "shk_dump", "shk_merge", "shk_multi_merge", "shk_import_shards", "shk_table_ptr"]
+           "shk_last_error_bits", "shk_insert_counted", "shk_dump", "shk_merge", "shk_multi_merge", "shk_import_shards", "shk_table_ptr", "shk_unitigs_add_reads"]
 
 _libs = {}
 
@@ -121,6 +121,47 @@ def load(path=None):
     L.shk_last_error_bits.restype = u32
     _libs[path] = L
     return L
+
+
+class UnitigSet:
+    """shk_unitig_set: the unitigs found so far, kept on the device of the context that feeds it"""
+
+    def __init__(self, ctx):
+        self.ctx, self.L = ctx, ctx.L
+        self.L.shk_unitig_set_new.restype = C.c_void_p
+        self.L.shk_unitig_set_free.argtypes = [C.c_void_p]
+        self.L.shk_unitigs_add_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                                 C.c_uint64, C.c_uint32, C.c_int]
+        self.L.shk_unitigs_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                 C.c_uint32, C.POINTER(C.c_uint64)]
+        self.L.shk_unitig_set_write.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p]
+        self.h = C.c_void_p(self.L.shk_unitig_set_new())
+
+    def add_seeds(self, seeds, counts, k, abundance_min, max_len, mark_traveled=True):
+        n = len(seeds)
+        sc = (C.c_uint32 * max(n, 1))(*counts)
+        self.ctx._chk(self.L.shk_unitigs_add_seeds(self.ctx.h, self.h, b"".join(seeds), sc, n, k, abundance_min, max_len,
+                                                   1 if mark_traveled else 0))
+
+    def add_reads(self, text, chunk_off, chunk_len, k, abundance_min, count_min, count_max, max_len):
+        """seeds of the reads in the FASTQ chunks + their walks; returns the number of seeds taken"""
+        buf = (C.c_char * len(text)).from_buffer_copy(text)
+        n = C.c_uint64()
+        self.ctx._chk(self.L.shk_unitigs_add_reads(self.ctx.h, self.h, C.cast(buf, C.c_void_p), 0, len(text), self.ctx._tab(chunk_off),
+                                                   self.ctx._tab(chunk_len), len(chunk_off), k, abundance_min, count_min, count_max,
+                                                   max_len, C.byref(n)))
+        return n.value
+
+    def write(self, k, path):
+        st = (C.c_uint64 * 6)()
+        self.ctx._chk(self.L.shk_unitig_set_write(self.h, k, path.encode(), C.cast(st, C.c_void_p)))
+        return dict(zip(("unitigs", "total_len", "rounds", "extensions", "duplicates", "truncated"), list(st)))
+
+    def close(self):
+        if self.h:
+            self.L.shk_unitig_set_free(self.h)
+            self.h = None
 
 
 def fixed_chunks(total_bytes, part_size):

@@ -406,3 +406,54 @@ def test_counted_insert_dump_merge_shards(shk):
     b = list({k: c for k, c in b}.items())
     F.check_merge(mk, 10, [a, b, F.pairs(rng, 10, 90, 1 << 12)])
     F.check_shards(mk, mk_shard, 10, F.pairs(rng, 10, 140, 300, cluster=(480, 64)), 2)   # a cluster across the shard border
+
+
+@pytest.mark.parametrize("mark", [0, 1])
+def test_unitig_set_invariants(shk, tmp_path, mark):
+    """the device-resident unitig engine (k_ug_walk and the finishing kernels) on the emulator: a genome with a repeat and a
+    small circle, seeds fed in two calls; the output is the compacted graph of the solid k-mers (tests/unitig_invariants.py)
+    with a well-formed record and link grammar; mark = 1 runs the traveled-bit / known-node protocol"""
+    import numpy as np
+    import unitig_invariants as UI
+    k, qb = 21, 12
+    g = synth.make_genome(220, 17)
+    g = np.concatenate([g[:130], g[40:72], g[130:]])
+    plasmid = synth.make_genome(70, 19)
+    fq = synth.make_fastq(g, 70, 60, 0.004, seed=19) + synth.make_fastq(np.concatenate([plasmid, plasmid, plasmid[:40]]), 24, 50, 0.0, seed=23, name_prefix="p")
+    offs, lens = chunks_by_records(fq, 40)
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    ctx = _ctx(shk, qb=qb, k=k, max_batch_bytes=len(fq) + 1024, max_batch_keys=1 << 14)
+    ctx.count_chunks(fq, offs, lens)
+    O = cqflibs.oracle()
+
+    def count(km):
+        fh, rh = O.nthash(km, k)
+        return q.count(min(fh, rh) & ((1 << (qb + 8)) - 1))
+    out = str(tmp_path / "u.fa")
+    u = shk.UnitigSet(ctx)
+    if mark:
+        n = u.add_reads(fq, offs, lens, k, 2, 2, 1000000, 4000)      # seeds chosen on the device, batch of all chunks
+        assert n >= 3
+        seeds = None
+    else:
+        seeds, counts = [], []
+        for line in fq.split(b"\n")[1::4]:
+            km = line[len(line) // 2 - k // 2:][:k]
+            if len(km) == k and b"N" not in km and count(km) >= 2:
+                seeds.append(km)
+                counts.append(count(km))
+        half = len(seeds) // 2
+        u.add_seeds(seeds[:half], counts[:half], k, 2, 4000, mark_traveled=False)
+        u.add_seeds(seeds[half:], counts[half:], k, 2, 4000, mark_traveled=False)
+    st = u.write(k, out)
+    u.close()
+    got = _read_unitigs(out, k)
+    seqs = [ln for ln in open(out, "rb").read().split(b"\n")[1::2] if ln]
+    assert st["unitigs"] == len(seqs) == len(got) and st["truncated"] == 0
+    if seeds is None:       # what the device took as seeds: every read's middle k-mer that is solid is in some unitig
+        seeds = [ln[len(ln) // 2 - k // 2:][:k] for ln in fq.split(b"\n")[1::4]]
+        seeds = [s for s in seeds if len(s) == k and b"N" not in s and count(s) >= 2]
+    UI.check(seqs, UI.Graph(count, k, 2), seeds=seeds)
+    assert any(len(x) == 70 + k - 1 and x[-(k - 1):] == x[:k - 1] for x in seqs)      # the plasmid came out as one pure circle
+    ctx.close()
+    q.free()

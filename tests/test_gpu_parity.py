@@ -355,6 +355,114 @@ def test_contiger_cli_unitig_set(tmp_path):
     q.free()
 
 
+def _oracle_counter(q, k, qb):
+    O = cqflibs.oracle()
+    mask = (1 << (qb + 8)) - 1
+
+    def count(km):
+        fh, rh = O.nthash(km, k)
+        return q.count(min(fh, rh) & mask)
+    return count
+
+
+def _fasta_seqs(path):
+    with open(path, "rb") as f:
+        return [ln for ln in f.read().split(b"\n")[1::2] if ln]
+
+
+@pytest.mark.parametrize("k,qb,mark", [(31, 17, 0), (47, 17, 1), (21, 17, 1), (64, 18, 1)])
+def test_unitigs_are_the_compacted_graph_of_the_filter(tmp_path, k, qb, mark):
+    """definition-level invariants (tests/unitig_invariants.py) of the device-built unitig set: a genome with repeats (real
+    branches), a circular plasmid seeded many times (pure circles), sequencing errors (tips, bubbles); with and without the
+    traveled-bit protocol. The filter the checker reads is the oracle's copy of the same table."""
+    import numpy as np
+    import shk
+    import unitig_invariants as UI
+    G = 24000
+    g = synth.make_genome(G, 41)
+    g = np.concatenate([g[:9000], g[2000:2600], g[9000:], g[15000:15300]])     # two repeats
+    plasmid = synth.make_genome(700, 43)
+    circ = np.concatenate([plasmid, plasmid, plasmid, plasmid[:200]])          # a tandem: reads run round the circle
+    fq = synth.make_fastq(g, 2600, 150, 0.004, seed=45) + synth.make_fastq(circ, 500, 120, 0.0, seed=47, name_prefix="p")
+    offs, lens = chunks_by_records(fq, 600)
+    ctx = _ctx(qb=qb, k=k, max_batch_bytes=len(fq) + 1024, max_batch_keys=1 << 20)
+    ctx.count_chunks(fq, offs, lens)
+    q, _, _ = oracle_t1(fq, offs, lens, k, qb)
+    assert ctx.blocks() == q.blocks()
+    count = _oracle_counter(q, k, qb)
+    seeds, counts = [], []
+    for line in fq.split(b"\n")[1::4]:
+        mid = len(line) // 2 - k // 2
+        km = line[mid:mid + k]
+        if len(km) < k or b"N" in km:
+            continue
+        c = count(km)
+        if 2 <= c <= 1000000:
+            seeds.append(km)
+            counts.append(c)
+    out = str(tmp_path / "u.fa")
+    u = shk.UnitigSet(ctx)
+    third = len(seeds) // 3
+    for a, b in ((0, third), (third, 2 * third), (2 * third, len(seeds))):     # several calls: the set accumulates
+        u.add_seeds(seeds[a:b], counts[a:b], k, 2, 4 * len(g), mark_traveled=bool(mark))
+    st = u.write(k, out)
+    u.close()
+    seqs = _fasta_seqs(out)
+    assert st["unitigs"] == len(seqs) and st["total_len"] == sum(len(s) for s in seqs) and len(seqs) >= 5 and st["truncated"] == 0
+    from test_emu_kernels import _read_unitigs
+    _read_unitigs(out, k)                       # record grammar and every L: link
+    UI.check(seqs, UI.Graph(count, k, 2), seeds=seeds)
+    ctx.close()
+    q.free()
+
+
+def test_contiger_cli_from_gpu_built_cqf(tmp_path):
+    """the two command lines chained as in the README (README.md:98, 131): bin/CQF-deNoise builds the .cqf on the GPU,
+    bin/Contiger loads it and writes unitigs.fa; the unitigs satisfy the compacted-graph invariants against the filter
+    (read back by the oracle from the same .cqf) and cover every seed's component"""
+    import subprocess
+    import numpy as np
+    import unitig_invariants as UI
+    from test_emu_kernels import _read_unitigs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bind = os.path.join(root, "sh-assembly_amd", "bin")
+    k, G = 47, 30000
+    g = synth.make_genome(G, 51)
+    g = np.concatenate([g[:14000], g[5000:5500], g[14000:]])
+    (tmp_path / "a.fq").write_bytes(synth.make_fastq(g, 2400, 150, 0.003, seed=53))
+    (tmp_path / "b.fq").write_bytes(synth.make_fastq(g, 2400, 150, 0.003, seed=55, name_prefix="s"))
+    (tmp_path / "files.txt").write_text("a.fq\nb.fq\n")
+    cqf = str(tmp_path / "k47.cqf")
+    r = subprocess.run([os.path.join(bind, "CQF-deNoise"), "-k", str(k), "-N", "500000", "-n", "30000", "-e", "0.003", "-f", "f",
+                        "-i", str(tmp_path / "files.txt"), "-o", cqf, "--part-size", "100000", "--overhead", "4000"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = str(tmp_path / "unitigs.fa")
+    r = subprocess.run([os.path.join(bind, "Contiger"), "-k", str(k), "-i", str(tmp_path / "files.txt"), "-c", cqf, "-o", out,
+                        "--part-size", "100000", "--overhead", "4000", "--batch-chunks", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    q = cqflibs.oracle().load(cqf)
+    qb = 0
+    while (q.L.orc_qf_size(q.h) // 89) * 64 > (1 << (qb + 1)):
+        qb += 1
+    hdr = open(cqf, "rb").read(128)
+    import struct
+    nslots = struct.unpack_from("<Q", hdr, 16)[0]
+    qb = nslots.bit_length() - 1
+    count = _oracle_counter(q, k, qb)
+    seqs = _fasta_seqs(out)
+    _read_unitigs(out, k)
+    fq = (tmp_path / "a.fq").read_bytes() + (tmp_path / "b.fq").read_bytes()
+    seeds = []
+    for line in fq.split(b"\n")[1::4]:
+        km = line[len(line) // 2 - k // 2:][:k]
+        if len(km) == k and b"N" not in km and 2 <= count(km) <= 1000000:
+            seeds.append(km)
+    UI.check(seqs, UI.Graph(count, k, 2), seeds=seeds)
+    assert len(seqs) >= 5 and "truncated: 0" in r.stderr
+    q.free()
+
+
 def test_full_size_schedule_independent_of_batching(tmp_path):
     """BASELINE size (C. elegans sizing: qb 29, one bench batch of 8 M reads = 832 M k-mers) with deNoise points inside
     the batch: table, counters, rounds and removed counts do not depend on how the 302 chunks are split into calls (the

@@ -216,3 +216,51 @@ def test_oracle_vs_reference_saturated_offsets():
         assert o.blocks() == r.blocks() == build_blocks(qb, qb + 8, denoise_survivors(qb, tot))
         o.free(), r.free()
     assert done >= 4
+
+
+def test_contiger_roll_sequence_equals_scratch_hashes():
+    """get_unitig_forward never hashes a k-mer from scratch inside its loop: it rolls with the REAL NTPC64, partly with the
+    forward/reverse arguments swapped (src/contig_assembly.cpp:3069, 3090, 3104, 3188-3189). Replayed here call for call
+    on the compiled base/nthash.hpp (oracle/_ref): every look-up key it forms -- the four successors, the siblings in
+    reverse orientation -- and the state it carries to the next step equal the canonical from-scratch hashes. This is
+    what lets the oracle (and the kernels' closed forms) hash from scratch / roll their own way."""
+    import random
+    if not cqflibs.have_ref():
+        pytest.skip("needs oracle/_ref")
+    R = cqflibs.ref()
+    rng = random.Random(3)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    bases = b"ACGT"
+
+    def rc(s):
+        return bytes(comp[c] for c in reversed(s))
+
+    def canon(s, k):
+        fh, rh = R.nthash(s, k)
+        return min(fh, rh)
+    for trial in range(300):
+        k = rng.randrange(21, 65)
+        cur = bytes(rng.choice(bases) for _ in range(k))
+        fh, rh = R.nthash(cur, k)                                   # :3052
+        for step in range(4):
+            fix = cur[1:]
+            # :3067-3070  kmer_hash = NTPC64(current_kmer[0], DNA_bases[x], K, kmer_hash, kmer_RC_hash) on copies
+            for x in bases:
+                f2, r2 = R.nthash_roll(cur[0], x, k, fh, rh)
+                assert min(f2, r2) == canon(fix + bytes([x]), k)
+            # :3090  NTPC64(current_kmer[0], 'A', K, current_kmer_hash, current_kmer_RC_hash): the state moves to fix + 'A'
+            fh, rh = R.nthash_roll(cur[0], ord("A"), k, fh, rh)
+            assert (fh, rh) == R.nthash(fix + b"A", k)
+            # :3091-3104  kmer = RC(current) with its last base replaced; NTPC64('T', x, K, kmer_RC_hash, kmer_hash): swapped
+            rcur = rc(cur)
+            for x in bases:
+                if x == rcur[k - 1]:
+                    continue
+                a, b = R.nthash_roll(ord("T"), x, k, rh, fh)          # (fhVal, rhVal) := (reverse, forward) of the state
+                assert min(a, b) == canon(rcur[:k - 1] + bytes([x]), k)
+            # :3184-3189  extension by base x: two swapped / unswapped rolls bring the state to the new current k-mer
+            x = rng.choice(bases)
+            rh, fh = R.nthash_roll(ord("T"), ord("A"), k, rh, fh)     # NTPC64('T', 'A', K, current_kmer_RC_hash, current_kmer_hash)
+            fh, rh = R.nthash_roll(ord("T"), x, k, fh, rh)            # NTPC64('T', x, K, current_kmer_hash, current_kmer_RC_hash)
+            cur = fix + bytes([x])
+            assert (fh, rh) == R.nthash(cur, k)
