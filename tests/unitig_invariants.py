@@ -59,9 +59,14 @@ class Graph:
         return seen
 
 
-def check(unitigs, graph, seeds=None, sample=None):
+def check(unitigs, graph, seeds=None, sample=None, key=None):
     """unitigs: list of sequences (bytes). seeds: k-mers the build started from (None: skip the coverage half of 2).
-    sample: check invariants 1 and 3 on this many unitigs only (2 needs all of them and is skipped then)."""
+    sample: check invariants 1 and 3 on this many unitigs only (2 needs all of them and is skipped then).
+    key: the filter key of a k-mer (canonical hash mod range). Give it when the build ran the traveled-bit protocol on
+    seeds taken from reads: the traveled bit belongs to the filter ENTRY, so a seed whose key another reachable k-mer
+    shares may have been skipped as "already traveled" (the reference notes "possible because of hash collisions",
+    :3082) -- the unitigs must then cover everything reachable from the seeds with unshared keys, and nothing that is
+    not reachable from all of them."""
     k = graph.k
     todo = unitigs
     if sample is not None and sample < len(unitigs):
@@ -92,4 +97,12 @@ def check(unitigs, graph, seeds=None, sample=None):
             seen[c] = 1
     if seeds is not None:
         want = graph.reachable(seeds)
-        assert set(seen) == want, (len(seen), len(want))
+        if key is None:
+            assert set(seen) == want, (len(seen), len(want))
+        else:
+            owners = {}
+            for c in want:
+                owners.setdefault(key(c), set()).add(c)
+            sure = [s for s in seeds if len(owners.get(key(canon(s)), ())) <= 1]
+            must = graph.reachable(sure)
+            assert must <= set(seen) <= want, (len(must), len(seen), len(want))
