@@ -26,12 +26,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -1451,7 +1451,7 @@ extern "C" int shk_select_seeds(shk_ctx *c, const void *text, int text_on_device
   if (dmalloc(&ds, nreads * k) || dmalloc(&dc, nreads)) return SHK_ERR_HIP;
   { ProfScope ps(c, KP_WALK);
     hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
-                       c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, nreads, k, count_min, count_max, use_traveled ? 1 : 2, ds, dc); }
+                       c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, (uint64_t)0, nreads, k, count_min, count_max, use_traveled ? 1 : 2, ds, dc); }
   HIPCHK(hipGetLastError());
   std::vector<char> hs(nreads * k);
   std::vector<uint32_t> hc(nreads);
@@ -1677,8 +1677,8 @@ static int ug_run(shk_unitig_set *u, uint32_t nactive, int mark) {
     u->h_scal[0] = u->ncontigs; u->h_scal[1] = 0; u->h_scal[2] = 0;
     HIPCHK(hipMemcpyAsync(u->d_scal, u->h_scal, 12, hipMemcpyHostToDevice, c->stream));
     u->G.next = u->d_list[cur ^ 1];
-    { ProfScope ps(c, KP_WALK);
-      hipLaunchKernelGGL(k_ug_walk, dim3((nactive + 63) / 64), dim3(64), 0, c->stream, u->G, (const uint32_t *)u->d_list[cur], nactive, c->tab[c->cur], c->q_lo,
+    { ProfScope ps(c, KP_UG_WALK);
+      hipLaunchKernelGGL(k_ug_walk, dim3((nactive + 7) / 8), dim3(64), 0, c->stream, u->G, (const uint32_t *)u->d_list[cur], nactive, c->tab[c->cur], c->q_lo,
                          c->nslots, c->cfg.hb, u->k, u->amin, mark ? 1 : 2, step, u->max_len); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(u->h_scal, u->d_scal, 12, hipMemcpyDeviceToHost, c->stream));
@@ -1740,24 +1740,38 @@ extern "C" int shk_unitigs_add_reads(shk_ctx *c, shk_unitig_set *u, const void *
     if (dmalloc(&u->d_seeds, nreads * k) || dmalloc(&u->d_counts, nreads)) return SHK_ERR_HIP;
     u->seeds_cap = nreads;
   }
-  rc = ug_reserve(u, (uint64_t)u->ncontigs + nreads + 16, nreads + 16);
-  if (rc) return rc;
-  { ProfScope ps(c, KP_WALK);
-    hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
-                       c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, nreads, k, count_min, count_max, 1, u->d_seeds, u->d_counts); }
-  u->h_scal[0] = u->ncontigs; u->h_scal[1] = 0; u->h_scal[2] = 0; u->h_scal[3] = 0;
-  HIPCHK(hipMemcpyAsync(u->d_scal, u->h_scal, 16, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_ug_seeds_from_reads, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, u->G, (const char *)u->d_seeds,
-                     (const uint32_t *)u->d_counts, nreads, k, u->d_list[0], u->d_scal + 3);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(u->h_scal, u->d_scal, 16, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (u->h_scal[2]) return finish(c, SHK_ERR_BATCH);
-  u->ncontigs = u->h_scal[0];
-  const uint32_t n = u->h_scal[3];
-  if (nseeds) *nseeds = n;
-  rc = ug_run(u, n, 1);
-  return finish(c, rc);
+  // The reference takes its seeds read by read: a read whose middle k-mer an earlier walk has already marked gives none
+  // (:1871-1873). Selecting all seeds of a batch at once would walk every unitig once per read that covers it, so the
+  // reads are taken in slices that grow geometrically: the walks of one slice mark their unitigs before the next, four
+  // times larger, slice looks at its reads -- the duplicates stay a small multiple of the number of unitigs.
+  uint64_t total_seeds = 0, lo = 0, slice = 16384;
+  if (const char *e = getenv("SHK_SEED_SLICE")) { long long v = atoll(e); if (v > 0) slice = (uint64_t)v; }
+  while (lo < nreads) {
+    const uint64_t hi = nreads - lo < slice ? nreads : lo + slice;
+    const uint64_t m = hi - lo;
+    rc = ug_reserve(u, (uint64_t)u->ncontigs + m + 16, m + 16);
+    if (rc) return finish(c, rc);
+    { ProfScope ps(c, KP_WALK);
+      hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
+                         c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, lo, hi, k, count_min, count_max, 1, u->d_seeds, u->d_counts); }
+    u->h_scal[0] = u->ncontigs; u->h_scal[1] = 0; u->h_scal[2] = 0; u->h_scal[3] = 0;
+    HIPCHK(hipMemcpyAsync(u->d_scal, u->h_scal, 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ug_seeds_from_reads, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, c->stream, u->G, (const char *)u->d_seeds,
+                       (const uint32_t *)u->d_counts, lo, hi, k, u->d_list[0], u->d_scal + 3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(u->h_scal, u->d_scal, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (u->h_scal[2]) return finish(c, SHK_ERR_BATCH);
+    u->ncontigs = u->h_scal[0];
+    const uint32_t n = u->h_scal[3];
+    total_seeds += n;
+    rc = ug_run(u, n, 1);
+    if (rc) return finish(c, rc);
+    lo = hi;
+    slice *= 4;
+  }
+  if (nseeds) *nseeds = total_seeds;
+  return finish(c, SHK_OK);
 }
 
 extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *out_path, shk_unitig_stats *stats) {
@@ -1788,6 +1802,17 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
     if ((uint64_t)n / SHK_SCAN_TILE + 2 > 8192) { rc = SHK_ERR_BATCH; break; }     // run_scan's scratch in the context
     if (dmalloc(&d_keep, (uint64_t)n + 1) || dmalloc(&d_lens, (uint64_t)n + 1) || dmalloc(&d_newid, (uint64_t)n + 2) || dmalloc(&d_off, (uint64_t)n + 2)) { rc = SHK_ERR_HIP; break; }
     hipLaunchKernelGGL(k_ug_check, dim3((n + 255) / 256), dim3(256), 0, c->stream, u->G, n, d_keep, d_lens);
+    if (getenv("SHK_UG_DEBUG")) {   // diagnostics: contigs by kind, state and last stop reason
+      std::vector<uint8_t> hs(n), hk(n), hp(n);
+      std::vector<uint32_t> hkeep(n);
+      hipMemcpy(hs.data(), u->G.state, n, hipMemcpyDeviceToHost); hipMemcpy(hk.data(), u->G.kind, n, hipMemcpyDeviceToHost);
+      hipMemcpy(hp.data(), u->G.stop, n, hipMemcpyDeviceToHost); hipMemcpy(hkeep.data(), d_keep, (size_t)n * 4, hipMemcpyDeviceToHost);
+      unsigned long long h[2][4][8] = {{{0}}}, kept[2] = {0, 0};
+      for (uint32_t i = 1; i < n; i++) { h[hk[i] & 1][hs[i] & 3][hp[i] & 7]++; kept[hk[i] & 1] += hkeep[i]; }
+      for (int kd = 0; kd < 2; kd++) for (int stt = 0; stt < 4; stt++) for (int sp = 0; sp < 8; sp++)
+        if (h[kd][stt][sp]) fprintf(stderr, "SHK_UG_DEBUG %s state %d stop %d: %llu\n", kd ? "seed" : "cand", stt, sp, h[kd][stt][sp]);
+      fprintf(stderr, "SHK_UG_DEBUG kept seeds %llu candidates %llu\n", kept[1], kept[0]);
+    }
     if (run_scan<uint32_t>(c, d_keep, n, nullptr, d_newid) || run_scan<uint32_t>(c, d_lens, n, nullptr, d_off)) { rc = SHK_ERR_HIP; break; }
     if (hipMemcpyAsync(c->h_pinned + 45, d_newid + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipMemcpyAsync(c->h_pinned + 46, d_off + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1796,7 +1821,7 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
     if (nunits == 0) break;
     if (dmalloc(&d_bases, total + 16) || dmalloc(&d_cnt, total + 16) || dmalloc(&d_uoff, nunits + 1) || dmalloc(&d_ulen, nunits + 1) ||
         dmalloc(&d_ul1, nunits + 1) || dmalloc(&d_med, nunits + 1) || dmalloc(&d_links, nunits * 8 + 8)) { rc = SHK_ERR_HIP; break; }
-    { ProfScope ps(c, KP_WALK);
+    { ProfScope ps(c, KP_UG_FINISH);
       hipLaunchKernelGGL(k_ug_emit, dim3((n + 63) / 64), dim3(64), 0, c->stream, u->G, n, (const uint32_t *)d_keep, (const uint64_t *)d_newid, (const uint64_t *)d_off,
                          c->tab[c->cur], c->q_lo, c->nslots, c->cfg.hb, k, u->amin, d_bases, d_cnt, d_uoff, d_ulen, d_ul1); }
     hipLaunchKernelGGL(k_ug_median, dim3((uint32_t)nunits), dim3(SHK_WAVE), 0, c->stream, (uint32_t)nunits, (const uint64_t *)d_uoff, (const uint32_t *)d_ulen,

@@ -202,9 +202,9 @@ __global__ void k_ug_add_seeds(ShkUG G, const char *seeds, const uint32_t *count
   shk_ug_init(G, id, w, k, counts[i], 1);
 }
 // seeds straight from the reads of a batch (k_select_seeds' per-read output: count 0 = no seed): compacted into new contigs
-__global__ void k_ug_seeds_from_reads(ShkUG G, const char *seeds, const uint32_t *counts, uint64_t nreads, uint32_t k,
+__global__ void k_ug_seeds_from_reads(ShkUG G, const char *seeds, const uint32_t *counts, uint64_t read_lo, uint64_t nreads, uint32_t k,
                                       uint32_t *active, uint32_t *nactive) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = read_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads || counts[r] == 0) return;
   shk_u128 w = 0;
   for (uint32_t j = 0; j < k; j++) {
@@ -219,135 +219,176 @@ __global__ void k_ug_seeds_from_reads(ShkUG G, const char *seeds, const uint32_t
 
 // get_unitig_forward for every contig of `active`, at most max_steps extensions each per launch (a contig that is not
 // done goes onto the `next` list again, as do the neighbours queued at a branch and seeds that turn round).
-__global__ void k_ug_walk(ShkUG G, const uint32_t *active, uint32_t nactive, uint8_t *tab, uint64_t q_lo, uint64_t nslots,
-                          uint32_t hb, uint32_t k, uint64_t amin, int mark, uint32_t max_steps, uint32_t max_len) {
+// EIGHT LANES PER CONTIG: a step's seven filter lookups are independent of each other, and a walk is one long chain
+// of dependent steps, so lane j of a group looks up neighbour j (0-3: the successors current[1..]+ACGT, 4-7: the
+// siblings, i.e. RC(current) with its last base replaced by ACGT; the lane of current itself idles). The group's
+// verdicts meet in a wave ballot; every lane keeps the walk's state and decides alike; lane 0 owns the contig's
+// records, a lane that found a candidate queues it itself.
+#define SHK_UG_LANES 8
+__global__ void __launch_bounds__(SHK_WAVE) k_ug_walk(ShkUG G, const uint32_t *active, uint32_t nactive, uint8_t *tab, uint64_t q_lo,
+                                                      uint64_t nslots, uint32_t hb, uint32_t k, uint64_t amin, int mark, uint32_t max_steps,
+                                                      uint32_t max_len) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nactive) return;
-  const uint32_t id = active[t];
-  if (G.state[id] != SHK_UG_OPEN) return;
+  const uint32_t grp = t / SHK_UG_LANES;
+  const unsigned sub = t % SHK_UG_LANES;                       // my neighbour
+  const unsigned gshift = (threadIdx.x & (SHK_WAVE - 1)) & ~(SHK_UG_LANES - 1u);   // my group's first lane in the wave
+  bool alive = grp < nactive;
+  const uint32_t id = alive ? active[grp] : 0;
+  if (alive && G.state[id] != SHK_UG_OPEN) alive = false;
   const uint64_t kmask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
   const shk_u128 wmask = shk_ug_mask(k);
-  shk_u128 win = ((shk_u128)G.cur_hi[id] << 64) | G.cur_lo[id];
-  shk_u128 rcw = ((shk_u128)G.rc_hi[id] << 64) | G.rc_lo[id];
-  shk_u128 first = ((shk_u128)G.first_hi[id] << 64) | G.first_lo[id];
-  uint64_t fh = G.fh[id], rh = G.rh[id], hmin = G.hmin[id];
-  uint32_t len = G.len[id];
-  uint8_t kind = G.kind[id];
+  shk_u128 win = 0, rcw = 0, first = 0;
+  uint64_t fh = 0, rh = 0, hmin = ~0ULL;
+  uint32_t len = 0;
+  uint8_t kind = 0;
+  if (alive) {
+    win = ((shk_u128)G.cur_hi[id] << 64) | G.cur_lo[id];
+    rcw = ((shk_u128)G.rc_hi[id] << 64) | G.rc_lo[id];
+    first = ((shk_u128)G.first_hi[id] << 64) | G.first_lo[id];
+    fh = G.fh[id]; rh = G.rh[id]; hmin = G.hmin[id];
+    len = G.len[id]; kind = G.kind[id];
+  }
   unsigned long long ext = 0;
   uint32_t steps = 0;
-  for (;;) {
-    if (kind & 4u) {                       // a fresh k-mer: hash it once
-      shk_ug_hash(win, k, &fh, &rh);
-      kind &= ~4u;
-      const uint64_t hc = fh < rh ? fh : rh;
-      if (hc < hmin) hmin = hc;
-    }
-    if (steps >= max_steps) {              // goes on in the next launch
-      G.cur_lo[id] = (uint64_t)win; G.cur_hi[id] = (uint64_t)(win >> 64);
-      G.rc_lo[id] = (uint64_t)rcw; G.rc_hi[id] = (uint64_t)(rcw >> 64);
-      G.fh[id] = fh; G.rh[id] = rh; G.hmin[id] = hmin; G.len[id] = len; G.kind[id] = kind;
-      G.next[atomicAdd(G.next_n, 1u)] = id;
-      break;
-    }
-    steps++;
-    const unsigned s0 = (unsigned)(win >> (2 * (k - 1))) & 3u;
-    // k-mers with current[1..] as prefix (:3064-3087)
-    const uint64_t fbase = shk_rol64(fh, 1) ^ shk_rol64(shk_code_seed(s0), k & 63);
-    const uint64_t rbase = shk_ror64(rh ^ shk_code_seed_rc(s0), 1);
-    uint32_t ncand = 0, nnode_after = 0, xc = 0, nbefore = 0;
-    uint8_t cand = 0;
-    uint32_t cc[8];
-    uint64_t cnt_x = 0, fh_x = 0, rh_x = 0;
-    uint8_t trav;
-    for (unsigned x = 0; x < 4; x++) {
-      const uint64_t f = fbase ^ shk_code_seed(x);
-      const uint64_t r = rbase ^ shk_rol64(shk_code_seed_rc(x), (k - 1) & 63);
-      const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, mark, &trav);
-      if (cnt >= amin) {
-        if (trav && shk_ug_find(G, ((win << 2) | x) & wmask)) nnode_after++;     // a known unitig start
-        else { ncand++; xc = x; cnt_x = cnt; fh_x = f; rh_x = r; cand |= (uint8_t)(1u << x); cc[x] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt; }
-      }
-    }
-    // k-mers with RC(current[1..]) as prefix: the other predecessors of my successors (:3090-3120). In the reverse
-    // orientation they are RC(current) with its last base replaced; base y there <=> sibling base 3 - y here
-    for (unsigned y = 0; y < 4; y++) {
-      if (y == 3u - s0) continue;
-      const unsigned z = 3u - y;
-      const uint64_t f = fh ^ shk_rol64(shk_code_seed(s0) ^ shk_code_seed(z), (k - 1) & 63);
-      const uint64_t r = rh ^ shk_code_seed_rc(s0) ^ shk_code_seed_rc(z);
-      const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, mark, &trav);
-      if (cnt >= amin) {
-        nbefore++;
-        if (!(trav && shk_ug_find(G, (rcw & ~(shk_u128)3) | y))) { cand |= (uint8_t)(16u << y); cc[4 + y] = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt; }
-      }
-    }
-    uint8_t stop = 0;
-    bool closed_ok = true;
-    if (nbefore || ncand + nnode_after > 1) {
-      // no linear extension (:3122-3165): my end is registered, the candidates become contigs of their own
-      stop = SHK_STOP_BRANCH;
-      closed_ok = shk_ug_put(G, rcw, id, false);
-      if (closed_ok) {
-        for (unsigned x = 0; x < 8; x++) {
-          if (!(cand & (1u << x))) continue;
-          const shk_u128 key = x < 4 ? (((win << 2) | x) & wmask) : ((rcw & ~(shk_u128)3) | (x - 4));
-          if (shk_ug_find(G, key)) continue;                 // (cheap pre-check: most neighbours are known already)
-          const uint32_t nid = atomicAdd(G.ncontigs, 1u);
-          if (nid >= G.cap) { atomicOr(G.flags, SHK_UG_E_CONTIGS); continue; }
-          if (shk_ug_put(G, key, nid, true)) {
-            shk_ug_init(G, nid, key, k, cc[x], 0);
-            G.next[atomicAdd(G.next_n, 1u)] = nid;
-            atomicAdd(&G.stats[3], 1ULL);
-          } else {
-            G.state[nid] = SHK_UG_UNUSED; G.len[nid] = 0;
-          }
-        }
-      }
-    } else if (ncand == 1) {
-      const shk_u128 nxt = ((win << 2) | xc) & wmask;
-      if (nxt == first) {
-        // a pure circle (:3176-3183): both keys go to this contig; the same circle cut elsewhere meets it in the circle set
-        stop = SHK_STOP_CIRCLE;
-        closed_ok = shk_ug_put(G, first, id, false) && shk_ug_put(G, rcw, id, false) && shk_ug_circle_put(G, hmin, id);
-      } else if (len >= max_len) {
-        stop = SHK_STOP_BUFFER;
-        atomicAdd(&G.stats[2], 1ULL);
-        closed_ok = shk_ug_put(G, rcw, id, false);
-      } else {
-        win = nxt;
-        rcw = (rcw >> 2) | ((shk_u128)(3u - xc) << (2 * (k - 1)));
-        fh = fh_x; rh = rh_x;
+  while (__ballot(alive)) {                                    // wave-uniform: groups that are done idle along
+    bool solid = false, node = false;
+    uint32_t mycnt = 0;
+    unsigned s0 = 0;
+    if (alive) {
+      if (kind & 4u) {                                         // a fresh k-mer: hash it once
+        shk_ug_hash(win, k, &fh, &rh);
+        kind &= ~4u;
         const uint64_t hc = fh < rh ? fh : rh;
         if (hc < hmin) hmin = hc;
-        len++; ext++;
-        (void)cnt_x;
-        continue;
       }
-    } else {
-      // one known unitig start ahead, or nothing (:3191-3216)
-      stop = nnode_after == 1 ? SHK_STOP_BRANCH : SHK_STOP_DEAD_END;
-      closed_ok = shk_ug_put(G, rcw, id, false);
+      if (steps >= max_steps) {                                // goes on in the next launch
+        if (sub == 0) {
+          G.cur_lo[id] = (uint64_t)win; G.cur_hi[id] = (uint64_t)(win >> 64);
+          G.rc_lo[id] = (uint64_t)rcw; G.rc_hi[id] = (uint64_t)(rcw >> 64);
+          G.fh[id] = fh; G.rh[id] = rh; G.hmin[id] = hmin; G.len[id] = len; G.kind[id] = kind;
+          G.next[atomicAdd(G.next_n, 1u)] = id;
+        }
+        alive = false;
+      }
     }
+    if (alive) {
+      steps++;
+      s0 = (unsigned)(win >> (2 * (k - 1))) & 3u;
+      uint64_t f, r;
+      shk_u128 key;
+      bool mine = true;
+      if (sub < 4) {
+        // k-mers with current[1..] as prefix (:3064-3087)
+        f = shk_rol64(fh, 1) ^ shk_rol64(shk_code_seed(s0), k & 63) ^ shk_code_seed(sub);
+        r = shk_ror64(rh ^ shk_code_seed_rc(s0), 1) ^ shk_rol64(shk_code_seed_rc(sub), (k - 1) & 63);
+        key = ((win << 2) | sub) & wmask;
+      } else {
+        // k-mers with RC(current[1..]) as prefix: the other predecessors of my successors (:3090-3120). In the reverse
+        // orientation they are RC(current) with its last base replaced; base y there <=> sibling base 3 - y here
+        const unsigned y = sub - 4, z = 3u - y;
+        mine = y != 3u - s0;
+        f = fh ^ shk_rol64(shk_code_seed(s0) ^ shk_code_seed(z), (k - 1) & 63);
+        r = rh ^ shk_code_seed_rc(s0) ^ shk_code_seed_rc(z);
+        key = (rcw & ~(shk_u128)3) | y;
+      }
+      if (mine) {
+        uint8_t trav;
+        const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, mark, &trav);
+        if (cnt >= amin) {
+          solid = true;
+          mycnt = cnt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cnt;
+          node = trav && shk_ug_find(G, key) != 0;             // a known unitig start
+        }
+      }
+    }
+    const unsigned solid_m = (unsigned)(__ballot(solid) >> gshift) & 0xFFu;
+    const unsigned node_m = (unsigned)(__ballot(node) >> gshift) & 0xFFu;
+    // ---- the verdict (every lane of the group computes the same); lane 0 registers what has to be registered
+    uint8_t stop = 0;
+    bool extend = false, branch = false, ok = false;
+    unsigned xc = 0;
+    const unsigned cand_m = solid_m & ~node_m;
+    if (alive) {
+      const uint32_t ncand = (uint32_t)__popc(cand_m & 0xFu), nnode_after = (uint32_t)__popc(node_m & 0xFu), nbefore = (uint32_t)__popc(solid_m >> 4);
+      if (nbefore || ncand + nnode_after > 1) {
+        // no linear extension (:3122-3165): my end is registered, the candidates become contigs of their own
+        stop = SHK_STOP_BRANCH; branch = true;
+        if (sub == 0) ok = shk_ug_put(G, rcw, id, false);
+      } else if (ncand == 1) {
+        xc = (unsigned)__ffs((int)(cand_m & 0xFu)) - 1;
+        const shk_u128 nxt = ((win << 2) | xc) & wmask;
+        if (nxt == first) {
+          // a pure circle (:3176-3183): both keys go to this contig; the same circle cut elsewhere meets it in the circle set
+          stop = SHK_STOP_CIRCLE;
+          if (sub == 0) ok = shk_ug_put(G, first, id, false) && shk_ug_put(G, rcw, id, false) && shk_ug_circle_put(G, hmin, id);
+        } else if (len >= max_len) {
+          stop = SHK_STOP_BUFFER;
+          if (sub == 0) { atomicAdd(&G.stats[2], 1ULL); ok = shk_ug_put(G, rcw, id, false); }
+        } else extend = true;
+      } else {
+        // one known unitig start ahead, or nothing (:3191-3216)
+        stop = nnode_after == 1 ? SHK_STOP_BRANCH : SHK_STOP_DEAD_END;
+        if (sub == 0) ok = shk_ug_put(G, rcw, id, false);
+      }
+    }
+    const bool closed_ok = __shfl((int)ok, (int)gshift) != 0;   // (every lane of the wave shuffles here, once per step)
+    uint32_t v = 0;
+    bool closing = alive && !extend;
+    if (alive && extend) {
+      const uint64_t f = shk_rol64(fh, 1) ^ shk_rol64(shk_code_seed(s0), k & 63) ^ shk_code_seed(xc);
+      const uint64_t r = shk_ror64(rh ^ shk_code_seed_rc(s0), 1) ^ shk_rol64(shk_code_seed_rc(xc), (k - 1) & 63);
+      win = ((win << 2) | xc) & wmask;
+      rcw = (rcw >> 2) | ((shk_u128)(3u - xc) << (2 * (k - 1)));
+      fh = f; rh = r;
+      const uint64_t hc = fh < rh ? fh : rh;
+      if (hc < hmin) hmin = hc;
+      len++;
+      if (sub == 0) ext++;
+    }
+    if (closing) {
+      if (branch && closed_ok && ((cand_m >> sub) & 1u)) {
+        // my neighbour is a candidate: it becomes a contig of one k-mer unless somebody has queued it already (:3133-3160)
+        const shk_u128 key = sub < 4 ? (((win << 2) | sub) & wmask) : ((rcw & ~(shk_u128)3) | (sub - 4));
+        if (!shk_ug_find(G, key)) {                            // (cheap pre-check: most neighbours are known already)
+          const uint32_t nid = atomicAdd(G.ncontigs, 1u);
+          if (nid >= G.cap) atomicOr(G.flags, SHK_UG_E_CONTIGS);
+          else if (shk_ug_put(G, key, nid, true)) {
+            shk_ug_init(G, nid, key, k, mycnt, 0);
+            G.next[atomicAdd(G.next_n, 1u)] = nid;
+            atomicAdd(&G.stats[3], 1ULL);
+          } else { G.state[nid] = SHK_UG_UNUSED; G.len[nid] = 0; }
+        }
+      }
+      // a seed after its first call (:1886-1904) looks its seed k-mer up
+      if (closed_ok && (kind & 1u) && !(kind & 2u) && stop != SHK_STOP_CIRCLE && sub == 0) v = shk_ug_find(G, first);
+    }
+    v = (uint32_t)__shfl((int)v, (int)gshift);
+    if (!closing) continue;
     // ---- this call of get_unitig_forward is over
-    G.cur_lo[id] = (uint64_t)win; G.cur_hi[id] = (uint64_t)(win >> 64);
-    G.rc_lo[id] = (uint64_t)rcw; G.rc_hi[id] = (uint64_t)(rcw >> 64);
-    G.fh[id] = fh; G.rh[id] = rh; G.hmin[id] = hmin; G.len[id] = len;
-    G.stop[id] = (uint8_t)((G.stop[id] << 4) | stop);
-    if (!closed_ok) { G.state[id] = SHK_UG_CLEARED; G.kind[id] = kind; atomicAdd(&G.stats[1], 1ULL); break; }
-    if ((kind & 1u) && !(kind & 2u) && stop != SHK_STOP_CIRCLE) {
-      // a seed after its first call (:1886-1904): unless the seed k-mer already belongs to a smaller contig, turn round
-      const uint32_t v = shk_ug_find(G, first);
-      if (v != 0 && v < id) { G.state[id] = SHK_UG_CLEARED; G.kind[id] = kind; atomicAdd(&G.stats[1], 1ULL); break; }
-      if (v == id) { G.state[id] = SHK_UG_CLOSED; G.kind[id] = kind; break; }
+    bool turn = false;
+    uint8_t nstate = SHK_UG_CLOSED;
+    if (!closed_ok) nstate = SHK_UG_CLEARED;
+    else if ((kind & 1u) && !(kind & 2u) && stop != SHK_STOP_CIRCLE) {
+      // unless the seed k-mer already belongs to a smaller contig (or to this one), turn round
+      if (v != 0 && v < id) nstate = SHK_UG_CLEARED;
+      else if (v != id) turn = true;
+    }
+    if (sub == 0) {
+      G.cur_lo[id] = (uint64_t)win; G.cur_hi[id] = (uint64_t)(win >> 64);
+      G.rc_lo[id] = (uint64_t)rcw; G.rc_hi[id] = (uint64_t)(rcw >> 64);
+      G.fh[id] = fh; G.rh[id] = rh; G.hmin[id] = hmin; G.len[id] = len;
+      G.stop[id] = (uint8_t)((G.stop[id] << 4) | stop);
+      if (nstate == SHK_UG_CLEARED) atomicAdd(&G.stats[1], 1ULL);
+    }
+    if (turn) {
       const shk_u128 nfirst = rcw, ncur = shk_ug_rc(first, k), nrc = first;
       first = nfirst; win = ncur; rcw = nrc;
-      G.first_lo[id] = (uint64_t)first; G.first_hi[id] = (uint64_t)(first >> 64);
-      G.l1[id] = len;
       kind |= 2u | 4u;
-      continue;                                              // second call, same thread, remaining step budget
+      if (sub == 0) { G.first_lo[id] = (uint64_t)first; G.first_hi[id] = (uint64_t)(first >> 64); G.l1[id] = len; }
+      continue;                                                // second call, same lanes, remaining step budget
     }
-    G.state[id] = SHK_UG_CLOSED; G.kind[id] = kind;
-    break;
+    if (sub == 0) { G.state[id] = nstate; G.kind[id] = kind; }
+    alive = false;
   }
   if (ext) atomicAdd(&G.stats[0], ext);
 }

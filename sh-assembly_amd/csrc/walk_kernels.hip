@@ -96,9 +96,10 @@ __global__ void k_extend_forward(uint8_t *tab, uint64_t q_lo, uint64_t nslots, u
 // looked up (and marked traveled when mark == 1, as count_key_value_set_traveled does); kept when it was not
 // traveled before and its count lies in [count_min, count_max]. One thread per read; out_counts[r] = 0 means none.
 __global__ void k_select_seeds(uint8_t *tab, uint64_t q_lo, uint64_t nslots, uint32_t hb, const uint8_t *text,
-                               const uint64_t *rd_start, const uint64_t *rd_end, uint64_t nreads, uint32_t k, uint64_t count_min,
+                               const uint64_t *rd_start, const uint64_t *rd_end, uint64_t read_lo, uint64_t nreads, uint32_t k, uint64_t count_min,
                                uint64_t count_max, int mark, char *out_seeds, uint32_t *out_counts) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // reads [read_lo, nreads) of the batch
+  const uint64_t r = read_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nreads) return;
   out_counts[r] = 0;
   const uint64_t st = rd_start[r], en = rd_end[r];

@@ -144,10 +144,16 @@ class UnitigSet:
         self.ctx._chk(self.L.shk_unitigs_add_seeds(self.ctx.h, self.h, b"".join(seeds), sc, n, k, abundance_min, max_len,
                                                    1 if mark_traveled else 0))
 
-    def add_reads(self, text, chunk_off, chunk_len, k, abundance_min, count_min, count_max, max_len):
-        """seeds of the reads in the FASTQ chunks + their walks; returns the number of seeds taken"""
-        buf = (C.c_char * len(text)).from_buffer_copy(text)
+    def add_reads(self, text, chunk_off, chunk_len, k, abundance_min, count_min, count_max, max_len, text_bytes=None):
+        """seeds of the reads in the FASTQ chunks + their walks; returns the number of seeds taken.
+        text: bytes, or an integer device pointer with text_bytes given"""
         n = C.c_uint64()
+        if isinstance(text, int):
+            self.ctx._chk(self.L.shk_unitigs_add_reads(self.ctx.h, self.h, C.c_void_p(text), 1, int(text_bytes), self.ctx._tab(chunk_off),
+                                                       self.ctx._tab(chunk_len), len(chunk_off), k, abundance_min, count_min, count_max,
+                                                       max_len, C.byref(n)))
+            return n.value
+        buf = (C.c_char * len(text)).from_buffer_copy(text)
         self.ctx._chk(self.L.shk_unitigs_add_reads(self.ctx.h, self.h, C.cast(buf, C.c_void_p), 0, len(text), self.ctx._tab(chunk_off),
                                                    self.ctx._tab(chunk_len), len(chunk_off), k, abundance_min, count_min, count_max,
                                                    max_len, C.byref(n)))

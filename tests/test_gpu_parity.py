@@ -468,6 +468,63 @@ def test_contiger_cli_from_gpu_built_cqf(tmp_path):
     q.free()
 
 
+def test_contiger_at_celegans_table_size(tmp_path):
+    """BASELINE config 3 at one-GPU scale: a C. elegans-sized filter (qb 29, 0.70 GiB) built on the GPU from 8 M reads
+    (60x of a 20 Mb genome), then Contiger on the device over the same reads (seeds chosen and walked batch by batch,
+    -s 4 / -x 4 as suits 60x). Checked: almost every genome k-mer lies in a unitig, unitigs are long, and a sample of
+    unitigs satisfies the compacted-graph invariants against the filter itself (device lookups)."""
+    import importlib.util
+    import random
+    import unitig_invariants as UI
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_contiger", os.path.join(root, "tools", "bench_contiger.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+
+    class A:
+        genome, reads, err, k, qb, amin, xmin, max_len, batch_chunks = 20_000_000, 8_000_000, 0.00234, 47, 29, 4, 4, 1 << 26, 64
+    torch, shk, ctx, text, offs, lens, _ = bc.build(A)
+    out = str(tmp_path / "unitigs.fa")
+    nseeds, st, t_walk, t_write, walk_ms, prof = bc.walk(shk, ctx, text, offs, lens, A, out)
+    del text
+    seqs = _fasta_seqs(out)
+    k = A.k
+    assert st["unitigs"] == len(seqs) and st["truncated"] == 0
+    nk = sum(len(s) - k + 1 for s in seqs)
+    assert 0.98 * A.genome <= nk <= 1.10 * A.genome            # the genome's k-mers (plus the solid error k-mers), each once
+    assert max(len(s) for s in seqs) > 5000
+    # sampled invariants against the filter on the device
+    O = cqflibs.oracle()
+    mask = (1 << (A.qb + 8)) - 1
+    sample = random.Random(2).sample(seqs, 80)
+    need = set()
+    W = 300
+    for s in sample:
+        idx = list(range(len(s) - k + 1))
+        if len(idx) > 2 * W:
+            idx = idx[:W + 1] + idx[-W - 1:]
+        for i in idx:
+            km = s[i:i + k]
+            for x in b"ACGT":
+                need.add(UI.canon(km[1:] + bytes([x])))
+                need.add(UI.canon(bytes([x]) + km[:-1]))
+            need.add(UI.canon(km))
+        for end in (s[-k:], UI.rc(s[:k])):
+            for x in b"ACGT":
+                nx = end[1:] + bytes([x])
+                for z in b"ACGT":
+                    need.add(UI.canon(bytes([z]) + nx[:-1]))
+    need = list(need)
+    keys = []
+    for km in need:
+        fh, rh = O.nthash(km, k)
+        keys.append(min(fh, rh) & mask)
+    cnt, _ = ctx.lookup(keys, mode=2)
+    table = dict(zip(need, cnt))
+    UI.check(sample, UI.Graph(lambda km: table[km], k, A.amin), sample=None, seeds=None, window=W)
+    ctx.close()
+
+
 def test_full_size_schedule_independent_of_batching(tmp_path):
     """BASELINE size (C. elegans sizing: qb 29, one bench batch of 8 M reads = 832 M k-mers) with deNoise points inside
     the batch: table, counters, rounds and removed counts do not depend on how the 302 chunks are split into calls (the

@@ -59,10 +59,11 @@ class Graph:
         return seen
 
 
-def check(unitigs, graph, seeds=None, sample=None, key=None):
+def check(unitigs, graph, seeds=None, sample=None, key=None, window=None):
     """unitigs: list of sequences (bytes). seeds: k-mers the build started from (None: skip the coverage half of 2).
     sample: check invariants 1 and 3 on this many unitigs only (2 needs all of them and is skipped then).
     key: the filter key of a k-mer (canonical hash mod range). Give it when the build ran the traveled-bit protocol on
+    window: on long unitigs look at the inner junctions of the first and last `window` k-mers only.
     seeds taken from reads: the traveled bit belongs to the filter ENTRY, so a seed whose key another reachable k-mer
     shares may have been skipped as "already traveled" (the reference notes "possible because of hash collisions",
     :3082) -- the unitigs must then cover everything reachable from the seeds with unshared keys, and nothing that is
@@ -75,9 +76,15 @@ def check(unitigs, graph, seeds=None, sample=None, key=None):
     for s in todo:
         assert len(s) >= k
         kms = [s[i:i + k] for i in range(len(s) - k + 1)]
-        for km in kms:
+        inner = list(zip(kms, kms[1:]))
+        if window is not None and len(kms) > 2 * window:
+            inner = inner[:window] + inner[-window:]
+            probe = kms[:window] + kms[-window:]
+        else:
+            probe = kms
+        for km in probe:
             assert graph.solid(km), "a unitig holds a k-mer below the abundance threshold"
-        for a, b in zip(kms, kms[1:]):          # inner junctions: the only way on, the only way back
+        for a, b in inner:                      # inner junctions: the only way on, the only way back
             assert graph.succ(a) == [b] and graph.pred(b) == [a], "a unitig runs through a branch"
         circle = len(kms) > 1 and kms[-1][1:] == kms[0][:-1] and graph.succ(kms[-1]) == [kms[0]] and graph.pred(kms[0]) == [kms[-1]]
         if circle:

@@ -54,7 +54,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
     ext = sum(len(s) - K for s, _, _ in out)
-    kms = prof.get("k_extend_forward", (0, 0.0))[1]
+    kms = prof.get("k_extend_forward+k_select_seeds", (0, 0.0))[1]
     steps = ext + 2 * len(out)          # every walk also pays the step at which it stops, twice
     print(json.dumps({"metric": "unitig extension (Contiger first slice)", "seeds": len(out), "extended_bases": ext,
                       "mean_unitig_len": (ext / max(len(out), 1)) + K, "wall_s": dt, "kernel_ms": kms,
