@@ -55,6 +55,8 @@ struct ShkMergeArgs {
   unsigned long long *n_over;
   const uint32_t *list;           // MODE 1 only: regions to rebuild (null = all, region = blockIdx.x)
   uint16_t *newchunks;            // [nregions * SHK_HCAP] first chunk of every NEW key of the region (null = off; needs want_hist)
+  uint32_t r0;                    // first region of this launch (a pass over more than 2^24 regions takes several launches:
+                                  // HIP limits a grid to fewer than 2^32 threads)
   int counted;                    // 1: the records' chunk field holds (multiplicity - 1) of a counted insert (insert_advance with
                                   // count > 1, gqf.c:2024-2136); every record takes part, no chunk statistics
 };
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const unsigned tid = threadIdx.x;
   const unsigned ngrp = blockDim.x;              // all waves of the group: staging, init, key folding
   constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave does the rest
-  const uint32_t r = (MODE == 1 && A.list) ? A.list[blockIdx.x] : blockIdx.x;
+  const uint32_t r = (MODE == 1 && A.list) ? A.list[blockIdx.x] : blockIdx.x + A.r0;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -816,7 +818,7 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
   __shared__ __attribute__((aligned(16))) uint8_t pack[SHK_SPILL_PACK_MAX];
   const unsigned tid = threadIdx.x;
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = blockIdx.x + A.r0;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint32_t *sm = A.summary + (size_t)SHK_SUM_STRIDE * r;
   if (sm[6]) return;

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_merge2(ShkMergeArgs A, ShkS
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
   __shared__ uint32_t qlen[SHK_REGION];
   const unsigned tid = threadIdx.x;
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = blockIdx.x + A.r0;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_dump(ShkMergeArgs A, uint32
                                                           uint64_t *counts, uint64_t cap, unsigned long long *stop) {
   __shared__ ShkRegionView<IMGB> V1, V2;
   const unsigned tid = threadIdx.x;
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = blockIdx.x + A.r0;
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
   const bool ok = shk_view_load<IMGB>(V1, A.tabA, A.finA, r, nq, A.nblocks, tid, A.err);

@@ -411,12 +411,21 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
   return SHK_OK;
 }
 
+// One launch per slice of at most 2^24 regions (a HIP grid holds fewer than 2^32 threads; a qb-33 filter has 2^25
+// regions): ARGS must name a ShkMergeArgs variable `A`, whose r0 the loop sets.
+#define SHK_REGION_SLICE (1u << 24)
+#define SHK_FOR_REGION_SLICES(c, A, nblk) \
+  for (uint32_t r0_ = 0, nblk = 0; r0_ < (c)->nregions && ((A).r0 = r0_, nblk = (c)->nregions - r0_ < SHK_REGION_SLICE ? (c)->nregions - r0_ : SHK_REGION_SLICE, true); r0_ += SHK_REGION_SLICE)
+
 template <int MODE>
-static void launch_merge(shk_ctx *c, const ShkMergeArgs &A) {
-  if (c->big_image)
-    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(c->merge_group), 0, c->stream, A);
-  else
-    hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(c->merge_group), 0, c->stream, A);
+static void launch_merge(shk_ctx *c, const ShkMergeArgs &A0) {
+  ShkMergeArgs A = A0;
+  SHK_FOR_REGION_SLICES(c, A, nblk) {
+    if (c->big_image)
+      hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
+    else
+      hipLaunchKernelGGL((k_region_merge<MODE, SHK_IMG_BLOCKS>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
+  }
 }
 
 struct MergeOut {
@@ -440,6 +449,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
   A->newchunks = nullptr;
   A->counted = c->counted;
+  A->r0 = 0;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -503,8 +513,11 @@ static int merge_write(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
       c->spill_big == c->big_image) {
     // the summary launch left lengths and encodings behind: placement only
     { ProfScope ps(c, KP_PLACE);
-      if (c->big_image) hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A);
-      else hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A); }
+      SHK_FOR_REGION_SLICES(c, A, nblk) {
+        if (c->big_image) hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A);
+        else hipLaunchKernelGGL((k_region_place<SHK_IMG_BLOCKS>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A);
+      }
+      A.r0 = 0; }
     if (c->spill_nover) {
       A.list = c->d_over_list;
       ProfScope ps(c, KP_MERGE_WRITE);
@@ -1282,8 +1295,10 @@ extern "C" int shk_dump(shk_ctx *c, uint64_t *keys, uint64_t *counts, uint64_t c
   c->spill_valid = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     { ProfScope ps(c, KP_MISC);
-      if (c->big_image) hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr);
-      else hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr); }
+      SHK_FOR_REGION_SLICES(c, A, nblk) {
+        if (c->big_image) hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr);
+        else hipLaunchKernelGGL((k_region_dump<0, SHK_IMG_BLOCKS>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, nper, no_offs, no_out, no_out, 0ULL, (unsigned long long *)nullptr);
+      } }
     uint32_t bits = 0;
     if (fetch_err(c, &bits)) return SHK_ERR_HIP;
     if ((bits & SHK_E_OLD_EXTENT) && !c->big_image) { c->big_image = 1; c->last_err_bits = 0; continue; }
@@ -1304,8 +1319,10 @@ extern "C" int shk_dump(shk_ctx *c, uint64_t *keys, uint64_t *counts, uint64_t c
   if (total) {
     ProfScope ps(c, KP_MISC);
     unsigned long long *sp = ref_iterator_end ? stop : nullptr;
-    if (c->big_image) hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
-    else hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
+    SHK_FOR_REGION_SLICES(c, A, nblk) {
+      if (c->big_image) hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
+      else hipLaunchKernelGGL((k_region_dump<1, SHK_IMG_BLOCKS>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, nper, (const uint64_t *)offs, m ? dk : no_out, m ? dc : no_out, m, sp);
+    }
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h_pinned + 46, stop, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1328,8 +1345,10 @@ static int merge2_run(shk_ctx *c, const ShkSrc2 &S, uint64_t *newd_out, uint64_t
     HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
     c->spill_valid = 0;
     { ProfScope ps(c, KP_MERGE_SUM);
-      if (c->big_image) hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S);
-      else hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S); }
+      SHK_FOR_REGION_SLICES(c, A, nblk) {
+        if (c->big_image) hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, S);
+        else hipLaunchKernelGGL((k_region_merge2<false, SHK_IMG_BLOCKS>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, S);
+      } }
     { ProfScope ps(c, KP_REGION_SCAN);
       const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
       hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b);
@@ -1347,8 +1366,10 @@ static int merge2_run(shk_ctx *c, const ShkSrc2 &S, uint64_t *newd_out, uint64_t
   }
   HIPCHK(hipMemsetAsync(c->tab[c->cur ^ 1], 0, c->table_bytes, c->stream));
   { ProfScope ps(c, KP_MERGE_WRITE);
-    if (c->big_image) hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS_BIG>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S);
-    else hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS>), dim3(c->nregions), dim3(SHK_WAVE), 0, c->stream, A, S); }
+    SHK_FOR_REGION_SLICES(c, A, nblk) {
+      if (c->big_image) hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS_BIG>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, S);
+      else hipLaunchKernelGGL((k_region_merge2<true, SHK_IMG_BLOCKS>), dim3(nblk), dim3(SHK_WAVE), 0, c->stream, A, S);
+    } }
   HIPCHK(hipGetLastError());
   c->cur ^= 1;
   *newd_out = newd; *added_out = added;
@@ -1447,8 +1468,9 @@ extern "C" int shk_select_seeds(shk_ctx *c, const void *text, int text_on_device
   if (rc) return finish(c, rc);
   *n_out = 0;
   if (nreads == 0) return finish(c, 0);
-  char *ds = nullptr; uint32_t *dc = nullptr;
-  if (dmalloc(&ds, nreads * k) || dmalloc(&dc, nreads)) return SHK_ERR_HIP;
+  struct Scratch { char *s = nullptr; uint32_t *c = nullptr; ~Scratch() { hipFree(s); hipFree(c); } } w;
+  if (dmalloc(&w.s, nreads * k) || dmalloc(&w.c, nreads)) return SHK_ERR_HIP;
+  char *ds = w.s; uint32_t *dc = w.c;
   { ProfScope ps(c, KP_WALK);
     hipLaunchKernelGGL(k_select_seeds, dim3((uint32_t)((nreads + 255) / 256)), dim3(256), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
                        c->cfg.hb, dtext, c->d_rd_start, c->d_rd_end, (uint64_t)0, nreads, k, count_min, count_max, use_traveled ? 1 : 2, ds, dc); }
@@ -1458,7 +1480,6 @@ extern "C" int shk_select_seeds(shk_ctx *c, const void *text, int text_on_device
   HIPCHK(hipMemcpyAsync(hs.data(), ds, nreads * k, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hc.data(), dc, nreads * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  hipFree(ds); hipFree(dc);
   uint32_t n = 0;
   for (uint64_t r = 0; r < nreads; r++)
     if (hc[r]) {                       // 0 = no seed from this read
@@ -1479,26 +1500,30 @@ extern "C" int shk_extend_forward(shk_ctx *c, const char *cur_kmers, const char 
   if (k < 2 || k > SHK_WALK_MAX_K || max_ext == 0) return SHK_ERR_ARG;
   if (n == 0) return SHK_OK;
   HIPCHK(hipSetDevice(c->dev));
-  char *dk = nullptr, *df = nullptr, *db = nullptr;
-  uint32_t *dc = nullptr, *dn = nullptr, *dnc = nullptr;
-  uint8_t *ds = nullptr, *dbr = nullptr;
+  // scratch of this call, released on every way out
+  struct Scratch {
+    char *dk = nullptr, *df = nullptr, *db = nullptr;
+    uint32_t *dc = nullptr, *dn = nullptr, *dnc = nullptr;
+    uint8_t *ds = nullptr, *dbr = nullptr;
+    ~Scratch() { hipFree(dk); hipFree(df); hipFree(db); hipFree(dc); hipFree(dn); hipFree(dnc); hipFree(ds); hipFree(dbr); }
+  } w;
   const size_t nk = (size_t)n * k, ne = (size_t)n * max_ext;
-  if (dmalloc(&dk, nk) || dmalloc(&df, nk) || dmalloc(&db, ne) || dmalloc(&dc, ne) || dmalloc(&dn, (size_t)n) || dmalloc(&ds, (size_t)n) || dmalloc(&dbr, (size_t)n) || dmalloc(&dnc, (size_t)n * 8))
+  if (dmalloc(&w.dk, nk) || dmalloc(&w.df, nk) || dmalloc(&w.db, ne) || dmalloc(&w.dc, ne) || dmalloc(&w.dn, (size_t)n) || dmalloc(&w.ds, (size_t)n) ||
+      dmalloc(&w.dbr, (size_t)n) || dmalloc(&w.dnc, (size_t)n * 8))
     return SHK_ERR_HIP;
-  HIPCHK(hipMemcpyAsync(dk, cur_kmers, nk, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(df, first_kmers, nk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w.dk, cur_kmers, nk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(w.df, first_kmers, nk, hipMemcpyHostToDevice, c->stream));
   { ProfScope ps(c, KP_WALK);
     hipLaunchKernelGGL(k_extend_forward, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
-                       c->cfg.hb, dk, df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, db, dc, dn, ds, dbr, dnc); }
+                       c->cfg.hb, w.dk, w.df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, w.db, w.dc, w.dn, w.ds, w.dbr, w.dnc); }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out_bases, db, ne, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(out_counts, dc, ne * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(out_n, dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(out_stop, ds, n, hipMemcpyDeviceToHost, c->stream));
-  if (out_branch) HIPCHK(hipMemcpyAsync(out_branch, dbr, n, hipMemcpyDeviceToHost, c->stream));
-  if (out_ncount) HIPCHK(hipMemcpyAsync(out_ncount, dnc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_bases, w.db, ne, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_counts, w.dc, ne * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_n, w.dn, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(out_stop, w.ds, n, hipMemcpyDeviceToHost, c->stream));
+  if (out_branch) HIPCHK(hipMemcpyAsync(out_branch, w.dbr, n, hipMemcpyDeviceToHost, c->stream));
+  if (out_ncount) HIPCHK(hipMemcpyAsync(out_ncount, w.dnc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  hipFree(dk); hipFree(df); hipFree(db); hipFree(dc); hipFree(dn); hipFree(ds); hipFree(dbr); hipFree(dnc);
   return finish(c, 0);
 }
 

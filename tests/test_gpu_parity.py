@@ -760,3 +760,148 @@ def test_build_then_dump_then_rebuild_is_identity():
     for x in (ctx, again):
         x.close()
     q.free()
+
+
+# ---------------------------------------------------------------- BASELINE configs 4 and 5 at one-GPU size
+def _torch_reads(nreads, genome_len, err, seed):
+    import importlib.util
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dev = torch.device("cuda", 0)
+    genome = torch.randint(0, 4, (genome_len,), device=dev, dtype=torch.uint8, generator=torch.Generator(device=dev).manual_seed(seed))
+    text = bench.gen_batch_torch(torch, genome, nreads, 150, err, 0, seed + 1, dev)
+    offs, lens = bench.chunk_table(nreads, 2 * 150 + bench.NAME_W + 6)
+    return torch, dev, text, offs, lens
+
+
+def _memory_report(ctx, nregions, batch_keys):
+    t = ctx.totals()
+    return {"table_bytes_x2": 2 * t.table_bytes, "spill_records": nregions * 1024, "first_chunk_records": nregions * 1024,
+            "key_words_x2": 2 * 8 * batch_keys}
+
+
+def test_config4_one_shard_of_eight_human_sized(tmp_path):
+    """BASELINE config 4 (human 30x, k = 31, quotient range sharded over 8 GPUs) as ONE rank sees it: shard 3 of a qb-34
+    filter (2^31 of its 2^34 slots + its own tail, a 3.0 GB table, 8.4 M regions) receives the keys it owns out of a
+    routed batch, through the collective flow with a one-rank group. Size-independent properties: counters equal the
+    routed words; the dump adds up; sampled lookups equal the words' multiplicities; inserting the batch again doubles
+    every count (linearity); a deNoise round removes exactly the singletons (up to the protected range ends); an
+    export / import round trip is the identity. Also prints the memory the shard needs."""
+    import torch.distributed as dist
+    from shk import dist as shkdist
+    torch, dev, text, offs, lens = _torch_reads(2_000_000, 40_000_000, 0.005, 61)
+    qb, k, S, me = 34, 31, 8, 3
+    nkeys = 2_000_000 * (150 - k + 1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx = _ctx(qb=qb, k=k, max_batch_bytes=64, max_batch_keys=nkeys + 4096, max_batch_reads=2_000_000 + 1024, shard_index=me, num_shards=S,
+                   min_denoise_len=0)
+        t = ctx.totals()
+        assert t.nslots == 1 << 31 and t.table_bytes > 2.9e9
+        print("config 4 shard memory:", _memory_report(ctx, (1 << 31) // 256, nkeys))
+        hb = qb + 8
+        _, nw = ctx.hash_chunks(text.data_ptr(), offs, lens, on_device=True, text_bytes=text.numel())
+        dp, cnts = ctx.route_words(nw, S)
+        assert sum(cnts) == nw and min(cnts) > 0.11 * nw                 # uniform hash: every owner gets about an eighth
+        words = shkdist.wrap_words(dp, nw, dev)
+        mine = words[sum(cnts[:me]): sum(cnts[:me + 1])].clone()
+        keys = mine & ((1 << hb) - 1)
+        assert int((keys >> (hb - 3)).min()) == me == int((keys >> (hb - 3)).max())     # the top three quotient bits name the owner
+        st = shkdist.ShardState(1 << 62, 0, dev)
+        ctx.stage_words(mine.data_ptr(), mine.numel())
+        out = shkdist.sharded_count(ctx, st, len(offs) * S)
+        uniq, mult = torch.unique(keys, return_counts=True)
+        t = ctx.totals()
+        assert out["kmers"] == mine.numel() == t.nelts and t.ndistinct == uniq.numel() == out["new_distinct"]
+        n = ctypes_dump_count(ctx)
+        assert n == t.ndistinct
+        pick = torch.randperm(uniq.numel(), device=dev)[:200000]
+        cnt, _ = ctx.lookup(uniq[pick].tolist(), mode=2)
+        assert cnt == mult[pick].tolist()
+        absent = [(me << (hb - 3)) | (int(x) & ((1 << (hb - 3)) - 1)) for x in torch.randint(0, 1 << 40, (20000,)).tolist()]
+        absent = [a for a in absent if a not in set(uniq[pick].tolist())]
+        cnt0, _ = ctx.lookup(absent[:5000], mode=2)
+        present = set(uniq.tolist()) if uniq.numel() < 3_000_000 else None
+        if present is not None:
+            assert all(c == 0 or a in present for a, c in zip(absent[:5000], cnt0))
+        # linearity: the same words again
+        ctx.stage_words(mine.data_ptr(), mine.numel())
+        shkdist.sharded_count(ctx, st, len(offs) * S)
+        t2 = ctx.totals()
+        assert t2.nelts == 2 * t.nelts and t2.ndistinct == t.ndistinct
+        cnt2, _ = ctx.lookup(uniq[pick][:50000].tolist(), mode=2)
+        assert cnt2 == (2 * mult[pick][:50000]).tolist()
+        # round trip through the host layout
+        blocks = ctx.blocks()
+        import hashlib
+        h1 = hashlib.sha256(blocks).hexdigest()
+        other = _ctx(qb=qb, k=k, max_batch_bytes=64, max_batch_keys=4096, shard_index=me, num_shards=S)
+        other.import_blocks(blocks, t2.nelts, t2.ndistinct)
+        del blocks
+        assert ctypes_dump_count(other) == t2.ndistinct
+        assert hashlib.sha256(other.blocks()).hexdigest() == h1
+        other.close()
+        ctx.close()
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+
+
+def ctypes_dump_count(ctx):
+    import ctypes as C
+    n = C.c_uint64()
+    assert ctx.L.shk_dump(ctx.h, None, None, 0, 0, 0, C.byref(n)) == 0
+    return n.value
+
+
+def test_config5_error_profile_sizing_and_qb33_filter(tmp_path):
+    """BASELINE config 5 (human 100x, k = 31, per-base error profile, deNoise rounds): the sizing of src/CQF-deNoise.cpp with
+    --errorProfile (true2falseKmer_DP) gives a qb-33 class filter; a whole qb-33 filter (2^33 slots, 11.9 GB table,
+    33.5 M regions) on ONE GPU takes batches with deNoise rounds firing at the t = 1 schedule's points. Properties:
+    counters add up across batches and rounds (nelts = presented - removed, every removed entry was a singleton), a
+    round leaves no removable singleton behind except the protected range ends, lookups match multiplicities."""
+    import ctypes as C
+    import torch
+    from test_host_logic import _sizing_api
+    rates = [0.001 + 0.019 * i / 149 for i in range(150)]
+    pf = tmp_path / "profile.txt"
+    pf.write_text("".join("%.17g\n" % r for r in rates))
+    L = _sizing_api()
+    out = (C.c_uint64 * 8)()
+    K, n_true, N = 31, 2_900_000_000, 300_000_000_000
+    L.shkh_size_filter_profile(K, n_true, N, str(pf).encode(), -1, 0.0, out)
+    qb_formula, rounds_formula = out[0], out[2]
+    assert qb_formula in (33, 34) and rounds_formula >= 1
+    qb = 33
+    torch_, dev, text, offs, lens = _torch_reads(3_000_000, 30_000_000, 0.01, 71)
+    nkeys = 3_000_000 * (150 - K + 1)
+    # a trigger that fires twice inside these reads (the data set is a sliver of the one the sizing is for)
+    ctx = _ctx(qb=qb, k=K, trigger=45_000_000, num_denoise=2, max_batch_bytes=64, max_batch_keys=nkeys + 4096, max_batch_reads=3_000_000 + 1024)
+    t = ctx.totals()
+    assert t.nslots == 1 << 33 and t.table_bytes > 11.8e9
+    print("config 5 filter memory:", _memory_report(ctx, (1 << 33) // 256, nkeys))
+    third = len(offs) // 3
+    presented = removed = rounds = 0
+    for a, b in ((0, third), (third, 2 * third), (2 * third, len(offs))):
+        st = ctx.count_chunks(text.data_ptr(), offs[a:b], lens[a:b], on_device=True, text_bytes=text.numel())
+        presented += st["kmers"]
+        removed += st["removed"]
+        rounds += st["denoise_rounds"]
+    t = ctx.totals()
+    assert rounds == 2 and t.rounds_left == 0 and removed > 0
+    assert t.nelts == presented - removed and t.ndistinct == ctypes_dump_count(ctx)
+    # an extra round now removes the singletons that arrived after the last one; a second extra round finds nothing more
+    # than the range-end singletons the first extra round protected (at most one per 2^20-slot range)
+    r1 = ctx.denoise()
+    r2 = ctx.denoise()
+    assert r1 > 0 and r2 <= (1 << 33) // (1 << 20) + 1
+    t2 = ctx.totals()
+    assert t2.nelts == t.nelts - r1 - r2 and t2.ndistinct == t.ndistinct - r1 - r2 == ctypes_dump_count(ctx)
+    ctx.close()
