@@ -352,7 +352,7 @@ def main():
             # the path-level figure; `traffic` = measured HBM bytes per step (separate --pmc passes)
             "roofline": {"bound": "hbm", "scope": "whole insert path: hash + partition + rebuild + deNoise rounds",
                          "achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": path_bytes / dt / HBM_PEAK, "traffic": step_traffic, "traffic_unit": "bytes/step (measured, all kernels)",
+                         "frac": path_bytes / dt / HBM_PEAK, "traffic": step_traffic, "traffic_unit": "bytes per step without a deNoise point (measured, all kernels; profiles/pmc_traffic.json)",
                          "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)",
                          "algorithmic_bytes_per_kmer": ALGO_BYTES_PER_KMER, "table_bytes": table_bytes},
             # the kernel with the most device time, on its MEASURED bytes (no algorithmic figure applies to one stage)
