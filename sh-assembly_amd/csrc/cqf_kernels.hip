@@ -53,8 +53,14 @@ struct ShkMergeArgs {
   uint8_t *spill;                 // [nregions * SHK_SPILL_STRIDE]
   uint32_t *over_list;            // regions whose runs did not fit the spill record (rebuilt by MODE 1 from this list)
   unsigned long long *n_over;
-  const uint32_t *list;           // MODE 1 only: regions to rebuild (null = all, region = blockIdx.x)
+  const uint32_t *list;           // regions to rebuild (null = all: region = blockIdx.x + r0)
   uint16_t *newchunks;            // [nregions * SHK_HCAP] first chunk of every NEW key of the region (null = off; needs want_hist)
+  // one-pass deNoise point (FUSED instantiation): words of chunks <= split are inserted BEFORE the round, the others after
+  uint32_t split;
+  uint32_t *isum;                 // [2 * nregions] (T, c) of the INTERMEDIATE table (after the chunks <= split, before the round)
+  uint8_t *ilens;                 // [256 * nregions] its run length per quotient
+  const uint64_t *prot_list;      // sorted quotients whose singleton the round's range walk protects (null on the first go)
+  uint32_t nprot;
   uint32_t r0;                    // first region of this launch (a pass over more than 2^24 regions takes several launches:
                                   // HIP limits a grid to fewer than 2^32 threads)
   int counted;                    // 1: the records' chunk field holds (multiplicity - 1) of a counted insert (insert_advance with
@@ -204,8 +210,9 @@ __device__ __forceinline__ void shk_store_image(const ShkMergeArgs &A, uint32_t 
 
 #define SHK_STAMP(i) do { if (A.dbg && (blockIdx.x & 63) == 0 && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&A.dbg[i], t_ - t_prev); t_prev = t_; } } while (0)
 
-template <int MODE, int IMGB>
+template <int MODE, int IMGB, bool FUSED = false>
 __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A) {
+  static_assert(!FUSED || MODE == 3, "the one-pass deNoise point is a spill-mode pass");
   constexpr bool WRITE = MODE == 1 || MODE == 2;   // builds the image and stores table B
   constexpr bool STAGE = WRITE || MODE == 3;       // keeps the runs' encodings per lane
   // LDS image of IMGB blocks: the region's own blocks + the blocks its runs may spill into.
@@ -213,7 +220,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
   static_assert(IMGB <= SHK_WAVE, "one lane per image block in the rank/select step");
   __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
-  __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch
+  __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch (FUSED: in the chunks <= split)
+  __shared__ uint32_t hcntB[FUSED ? SHK_HCAP : 1];      // FUSED: occurrences in the chunks behind the split
+  __shared__ uint32_t qcnt_i[FUSED ? SHK_REGION : 1];   // FUSED: run length per quotient in the intermediate table
+  __shared__ uint32_t s_added_b;
   __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
   __shared__ uint16_t qoff[SHK_REGION + 2];
   __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const unsigned tid = threadIdx.x;
   const unsigned ngrp = blockDim.x;              // all waves of the group: staging, init, key folding
   constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave does the rest
-  const uint32_t r = (MODE == 1 && A.list) ? A.list[blockIdx.x] : blockIdx.x + A.r0;
+  const uint32_t r = A.list ? A.list[blockIdx.x] : blockIdx.x + A.r0;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -248,7 +258,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const uint32_t ohi = old_any ? (uint32_t)((fa1 - q0) > 0xFFFFFFF ? 0xFFFFFFF : (fa1 - q0)) : olo;
   uint32_t nblk_old = old_any ? (ohi + 63) / 64 : 0;
   if (nblk_old < nown) nblk_old = nown;
-  if (tid == 0) { s_fail = 0; s_added = 0; s_nlist = 0; }
+  if (tid == 0) { s_fail = 0; s_added = 0; s_nlist = 0; s_added_b = 0; }
   // hash slots in use, in order of first insertion (lives in `stage`, which is idle until the merge pass)
   uint16_t *slist = reinterpret_cast<uint16_t *>(stage);
   bool fatal = false;
@@ -264,6 +274,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   if ((MODE == 0 || MODE == 3) && !old_any && !fatal && (!A.words || A.region_base[r] == A.region_base[r + 1])) {
     if (tid < SHK_SUM_STRIDE) A.summary[(size_t)SHK_SUM_STRIDE * r + tid] = 0;
     if (MODE == 3 && tid < SHK_WAVE) reinterpret_cast<uint32_t *>(A.spill + (size_t)r * SHK_SPILL_STRIDE)[tid] = 0;
+    if (FUSED) {
+      if (tid < 2) A.isum[2 * (size_t)r + tid] = 0;
+      if (tid < SHK_WAVE) reinterpret_cast<uint32_t *>(A.ilens + (size_t)r * SHK_REGION)[tid] = 0;
+    }
     return;
   }
 
@@ -273,8 +287,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
     uint32_t *dst = reinterpret_cast<uint32_t *>(oimg);
     if (!(A.ablate & 64)) for (uint32_t i = tid; i < (nbytes + 3) / 4; i += ngrp) dst[i] = src[i];
-    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; }
-    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) qcnt[i] = 0;
+    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; if (FUSED) hcntB[i] = 0; }
+    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) { qcnt[i] = 0; if (FUSED) qcnt_i[i] = 0; }
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
@@ -289,7 +303,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // wave), so the probe loop is written branch-free: every lane executes every LDS operation, with
   // operands that make it a no-op for lanes that have nothing (more) to insert -- a compare value no
   // slot can hold, min with ~0, add 0. Four words per lane probe together; the loop condition is wave-uniform.
-  uint32_t my_added = 0;
+  uint32_t my_added = 0, my_added_b = 0;
   if (A.words && !fatal && !(A.ablate & 1)) {
     const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
     const unsigned lane = shk_lane();
@@ -305,7 +319,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         wv[u] = i < nw ? wp[i] : ~0u;
       }
       uint32_t h[4], want[4], chk[4], wgt[4];
-      bool pend[4];
+      bool pend[4], bef[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         // record = (quotient in region << 8 | remainder) << SHK_CHUNK_BITS | chunk (k_rp_scatter, last level)
@@ -319,8 +333,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         want[u] = tag << SHK_CHUNK_BITS;
         chk[u] = chunk;
         wgt[u] = A.counted ? chunk + 1u : 1u;
+        bef[u] = FUSED && chunk <= A.split;
         h[u] = (__umul24(tag, 40503u) & 0xFFFFu) >> (16 - SHK_HCAP_LOG2);   // 16-bit multiplicative hash, full-rate multiply
-        my_added += pend[u] ? wgt[u] : 0u;
+        my_added += (pend[u] && !bef[u]) ? wgt[u] : 0u;
+        if (FUSED) my_added_b += (pend[u] && bef[u]) ? wgt[u] : 0u;
       }
       if (A.ablate & 256) continue;   // diagnostics: loads + setup only
       uint32_t guard = 0;
@@ -344,7 +360,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
           }
           if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
-          atomicAdd(&hcnt[h[u]], match ? wgt[u] : 0u);
+          if (FUSED) {
+            atomicAdd(&hcnt[h[u]], (match && bef[u]) ? wgt[u] : 0u);
+            atomicAdd(&hcntB[h[u]], (match && !bef[u]) ? wgt[u] : 0u);
+          } else atomicAdd(&hcnt[h[u]], match ? wgt[u] : 0u);
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }
@@ -356,10 +375,12 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (__ballot(hfull) && hfull) atomicOr(&s_fail, SHK_E_HASH_FULL);
   }
   if (my_added) atomicAdd(&s_added, my_added);
+  if (FUSED && my_added_b) atomicAdd(&s_added_b, my_added_b);
   __syncthreads();
   // the helper waves are done: one wave carries on (its barriers below are wave-local)
   if (tid >= nthr) return;
   my_added = tid == 0 ? s_added : 0;
+  my_added_b = (FUSED && tid == 0) ? s_added_b : 0;
   SHK_STAMP(1);   // key folding
 
   // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
@@ -445,6 +466,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // and (write modes) the run's encoding staged per lane
   uint32_t my_new = 0, my_removed = 0, my_before = 0;
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  ShkMP mine_i; mine_i.a = 0; mine_i.b = SHK_NEG_INF;   // FUSED: the same for the intermediate table
   uint32_t st_used = 0;            // staged bytes of this lane
   bool st_over = false;            // a run did not fit: this lane re-merges at placement time
   uint8_t *mystage = stage + tid * SHK_STAGE_STRIDE;
@@ -472,7 +494,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     constexpr uint32_t NONE = 0xFFFFFFu;
     uint32_t ncomp = NONE;                                                   // quotient << 8 | remainder of the next new key
     if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
-    uint32_t curq = 0xFFFFFFFFu, len = 0;
+    uint32_t curq = 0xFFFFFFFFu, len = 0, ilen = 0;
     while (ohas || ni < ne) {
       const uint32_t ocomp = ohas ? ((oq << 8) | orem) : NONE;
       const uint32_t comp = ocomp < ncomp ? ocomp : ncomp;
@@ -484,11 +506,53 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           ShkMP m; m.a = len; m.b = (long long)curq + len;
           mine = shk_mp_compose(mine, m);
         }
-        curq = eq; len = 0;
+        if (FUSED && ilen) {
+          qcnt_i[curq] = ilen;
+          ShkMP m; m.a = ilen; m.b = (long long)curq + ilen;
+          mine_i = shk_mp_compose(mine_i, m);
+        }
+        curq = eq; len = 0; ilen = 0;
       }
       uint64_t total = 0;
       bool is_new = false;
       uint32_t mc = 0, nhx = 0;
+      if (FUSED) {
+        // one-pass deNoise point: cb = the key's count when the round runs (old + chunks <= split), ca = what arrives behind it
+        uint64_t cb = take_old ? ocnt : 0, ca = 0;
+        if (take_old) {
+          opos += on;
+          if (opos <= oend) on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
+          else if (occ4) {
+            oq = qa + (uint32_t)__ffs((int)occ4) - 1; occ4 &= occ4 - 1;
+            jr++;
+            oprev = oend + 1;
+            oend = orend[jr];
+            opos = oprev > oq ? oprev : oq;
+            on = shk_img_dec_fast(oimg, opos, oend, &orem, &ocnt);
+          } else ohas = false;
+        }
+        if (take_new) {
+          cb += hcnt[nh]; ca = hcntB[nh];
+          ni++;
+          ncomp = NONE;
+          if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
+        }
+        if (cb) ilen += shk_enc_len_fast(rem, cb);            // its slots in the intermediate table
+        bool prot = false;
+        if (cb == 1) {
+          if (A.prot_list) {                                   // a singleton the range walk leaves alone? (sorted list, few entries)
+            const uint64_t gq = q0 + eq;
+            uint32_t lo2 = 0, hi2 = A.nprot;
+            while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (A.prot_list[mid] < gq) lo2 = mid + 1; else hi2 = mid; }
+            prot = lo2 < A.nprot && A.prot_list[lo2] == gq;
+          }
+          if (!prot) my_removed++;
+        }
+        const uint64_t kept = cb >= 2 ? cb : (prot ? 1 : 0);
+        total = kept + ca;
+        if (total == 0) continue;
+        if (kept == 0) my_new++;                               // (a dropped key that comes back counts as new, as after the reference's sweep)
+      } else {
       if (take_old) {
         total = ocnt;
         if (A.denoise) {
@@ -517,7 +581,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
       } else is_new = false;
       if (total == 0) continue;
-      if (is_new) {
+      }
+      if (!FUSED && is_new) {
         my_new++;
         if (MODE != 1 && A.want_hist) {
           // exact mode: the key is only flagged here and its first chunk collected below (the count
@@ -556,8 +621,38 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       ShkMP m; m.a = len; m.b = (long long)curq + len;
       mine = shk_mp_compose(mine, m);
     }
+    if (FUSED && ilen) {
+      qcnt_i[curq] = ilen;
+      ShkMP m; m.a = ilen; m.b = (long long)curq + ilen;
+      mine_i = shk_mp_compose(mine_i, m);
+    }
   }
   SHK_STAMP(4);   // merge pass
+  if (FUSED) {
+    // the intermediate table's (T, c) and run lengths: what the range walk of the round needs to know about this region
+    ShkMP inc_i = mine_i;
+    for (int d = 1; d < SHK_WAVE; d <<= 1) {
+      ShkMP y;
+      y.a = __shfl_up(inc_i.a, d);
+      y.b = __shfl_up(inc_i.b, d);
+      if (tid >= (unsigned)d) inc_i = shk_mp_compose(y, inc_i);
+    }
+    uint32_t l4 = 0;
+    bool big = false;
+#pragma unroll
+    for (uint32_t j = 0; j < SHK_REGION / nthr; j++) {
+      const uint32_t li = qcnt_i[tid * (SHK_REGION / nthr) + j];
+      if (li > 255) big = true;
+      l4 |= (li & 255u) << (8 * j);
+    }
+    reinterpret_cast<uint32_t *>(A.ilens + (size_t)r * SHK_REGION)[tid] = l4;
+    if (__ballot(big) && tid == 0) atomicOr(A.err, SHK_E_FUSED);
+    if (tid == SHK_WAVE - 1) {
+      A.isum[2 * (size_t)r] = fatal ? 0 : (uint32_t)inc_i.a;
+      A.isum[2 * (size_t)r + 1] = (!fatal && inc_i.b > 0) ? (uint32_t)inc_i.b : 0;
+      if (inc_i.a > 0xFFFF) atomicOr(A.err, SHK_E_FUSED);
+    }
+  }
   // wave scan of the free-pointer functions (lane order = quotient order)
   ShkMP incl = mine;
   for (int d = 1; d < SHK_WAVE; d <<= 1) {
@@ -576,7 +671,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // per-region statistics (summed later by k_region_scan_c / k_stats_reduce: no same-address atomics)
   if (MODE != 1) {
     const uint32_t t_added = shk_wave_incl_add(my_added), t_new = shk_wave_incl_add(my_new),
-                   t_removed = shk_wave_incl_add(my_removed), t_before = shk_wave_incl_add(my_before);
+                   t_removed = shk_wave_incl_add(my_removed), t_before = shk_wave_incl_add(FUSED ? my_added_b : my_before);
     if (tid == SHK_WAVE - 1) {
       uint32_t *sm = A.summary + (size_t)SHK_SUM_STRIDE * r;
       sm[0] = fatal ? 0 : (uint32_t)tot.a;
@@ -619,6 +714,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     if (tid == 0) {
       A.summary[(size_t)SHK_SUM_STRIDE * r + 6] = over ? 1 : 0;
       if (over) A.over_list[atomicAdd(A.n_over, 1ULL)] = r;
+      if (over && FUSED) atomicOr(A.err, SHK_E_FUSED);        // (the write pass for such regions does not know the split)
     }
     if (!over) {
       const uint32_t ex = sincl - st_used;
@@ -940,22 +1036,23 @@ __global__ void k_stats_reduce(const uint32_t *summary, uint32_t nregions, unsig
 
 // ---------------------------------------------------------------- free pointers
 // fin[r+1] = max(fin[r] + T_r, region start + c_r), as a 3-launch scan over tiles of regions.
-__device__ __forceinline__ ShkMP shk_region_mp(const uint32_t *summary, uint32_t r, uint32_t nregions) {
+__device__ __forceinline__ ShkMP shk_region_mp(const uint32_t *summary, uint32_t r, uint32_t nregions, uint32_t stride = SHK_SUM_STRIDE) {
   ShkMP m; m.a = 0; m.b = SHK_NEG_INF;
   if (r < nregions) {
-    m.a = summary[(size_t)SHK_SUM_STRIDE * r];
-    const uint32_t c = summary[(size_t)SHK_SUM_STRIDE * r + 1];
+    m.a = summary[(size_t)stride * r];
+    const uint32_t c = summary[(size_t)stride * r + 1];
     if (c) m.b = (long long)r * SHK_REGION + c;
   }
   return m;
 }
 // a: one workgroup per tile -> the tile's composed function
-__global__ void k_region_scan_a(const uint32_t *summary, uint32_t nregions, long long *tile_a, long long *tile_b) {
+// (stride = words per region record: SHK_SUM_STRIDE for the summaries, 2 for the intermediate table of a one-pass deNoise point)
+__global__ void k_region_scan_a(const uint32_t *summary, uint32_t nregions, long long *tile_a, long long *tile_b, uint32_t stride = SHK_SUM_STRIDE) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
   const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
-  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, base + threadIdx.x * per + j, nregions));
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, base + threadIdx.x * per + j, nregions, stride));
   ShkMP tot;
   shk_block_exscan_mp(mine, &tot, mpa, mpb);
   if (threadIdx.x == 0) { tile_a[blockIdx.x] = tot.a; tile_b[blockIdx.x] = tot.b; }
@@ -981,14 +1078,15 @@ __global__ void k_region_scan_b(const long long *tile_a, const long long *tile_b
 }
 // c: one workgroup per tile: fin[] for its regions + the capacity checks
 __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, const long long *tile_f, uint64_t xnslots,
-                                uint32_t img_slots, uint64_t *fin, unsigned long long *counters, uint32_t *err) {
+                                uint32_t img_slots, uint64_t *fin, unsigned long long *counters, uint32_t *err,
+                                uint32_t stride = SHK_SUM_STRIDE) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
   const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
   const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
   const uint32_t r0 = base + threadIdx.x * per;
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
-  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, r0 + j, nregions));
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, r0 + j, nregions, stride));
   ShkMP tot;
   ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
   long long f = shk_mp_apply(pre, tile_f[blockIdx.x]);
@@ -996,17 +1094,18 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t r = r0 + j;
     if (r >= nregions) break;
-    const ShkMP m = shk_region_mp(summary, r, nregions);
+    const ShkMP m = shk_region_mp(summary, r, nregions, stride);
     f = shk_mp_apply(m, f);
     fin[r + 1] = (uint64_t)f;
     if (m.a > 0 && f - (long long)r * SHK_REGION > (long long)img_slots) atomicOr(err, SHK_E_NEW_EXTENT);
     if ((uint64_t)f > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
   }
   // statistics of this tile's regions
+  if (stride >= 6)
   for (int z = 0; z < 4; z++) {
     uint64_t v = 0;
     for (uint32_t j = 0; j < per; j++)
-      if (r0 + j < nregions) v += summary[(size_t)SHK_SUM_STRIDE * (r0 + j) + 2 + z];
+      if (r0 + j < nregions) v += summary[(size_t)stride * (r0 + j) + 2 + z];
     const uint64_t t = shk_block_sum64(v, scratch64);
     if (threadIdx.x == 0 && t) atomicAdd(&counters[z], (unsigned long long)t);
   }
@@ -1134,6 +1233,120 @@ __global__ void k_denoise_marks(uint8_t *tab, uint64_t nslots, uint64_t xnslots,
     cur = shk_g_first_nonempty(tab, end + 1, nblocks, xnslots);
   }
   *nmarked = marked;
+}
+
+// The same range walk on a table that has not been written: the INTERMEDIATE table of a one-pass deNoise point, known
+// through its free pointer at every region start (fin) and its run length per quotient (lens, one byte each). Slot s is
+// in use iff the free pointer behind quotient s lies beyond s; "first non-empty" is the next quotient with a run
+// (find_first_nonempty_slot looks at the occupieds bits, gqf.c:751-774). Protected singletons are reported as quotients
+// (a one-slot cluster sits on its home slot). The ranges follow one another (each starts where the previous one ended),
+// but inside a step ONE WAVE works on a whole region at a time: lane i owns quotients 4i..4i+3 of the region, a
+// max-plus scan over the lanes gives every lane the free pointer in front of its quotients (the region's own anchor is
+// fin[r], so regions are independent), ballots find the first empty slot / the next run.
+struct ShkVRegion {            // what a lane knows of region r after shk_vregion()
+  uint64_t q0;                 // region's first quotient
+  uint64_t fpre;               // free pointer in front of my first quotient
+  uint32_t l4;                 // my four run lengths (one byte each)
+};
+__device__ __forceinline__ ShkVRegion shk_vregion(const uint64_t *fin, const uint8_t *lens, uint64_t nslots, uint64_t r, unsigned lane) {
+  ShkVRegion R;
+  R.q0 = r << SHK_REGION_LOG2;
+  const uint64_t myq = R.q0 + 4 * lane;
+  R.l4 = myq < nslots ? reinterpret_cast<const uint32_t *>(lens + R.q0)[lane] : 0u;   // (regions are whole: nslots is a multiple of 64, lens of absent quotients are 0)
+  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++) {
+    const uint32_t l = (R.l4 >> (8 * j)) & 255u;
+    if (l) { ShkMP m; m.a = l; m.b = (long long)(myq + j) + l; mine = shk_mp_compose(mine, m); }
+  }
+  ShkMP incl = mine;
+  for (int d = 1; d < SHK_WAVE; d <<= 1) {
+    ShkMP y;
+    y.a = __shfl_up(incl.a, d);
+    y.b = __shfl_up(incl.b, d);
+    if (lane >= (unsigned)d) incl = shk_mp_compose(y, incl);
+  }
+  ShkMP pre;
+  pre.a = __shfl_up(incl.a, 1);
+  pre.b = __shfl_up(incl.b, 1);
+  if (lane == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
+  R.fpre = (uint64_t)shk_mp_apply(pre, (long long)fin[r]);
+  return R;
+}
+__global__ void __launch_bounds__(SHK_WAVE) k_denoise_marks_virtual(const uint64_t *fin, const uint8_t *lens, const uint32_t *isum, uint64_t nslots,
+                                                                    uint64_t xnslots, uint64_t min_len, uint64_t *prot, uint32_t cap,
+                                                                    unsigned long long *nprot) {
+  if (blockIdx.x != 0) return;
+  const unsigned lane = threadIdx.x & (SHK_WAVE - 1);
+  const uint64_t nregions = (nslots + SHK_REGION - 1) / SHK_REGION;
+  // free pointer in front of quotient x and behind it (wave-uniform results)
+  auto fp_at = [&](uint64_t x, uint64_t *behind) -> uint64_t {
+    const uint64_t r = x >> SHK_REGION_LOG2;
+    if (r >= nregions) { *behind = fin[nregions]; return fin[nregions]; }
+    const ShkVRegion R = shk_vregion(fin, lens, nslots, r, lane);
+    uint64_t f = R.fpre, fb = R.fpre;
+    const unsigned owner = (unsigned)((x - R.q0) >> 2), jx = (unsigned)(x & 3);
+    for (unsigned j = 0; j <= jx; j++) {
+      const uint32_t l = (R.l4 >> (8 * j)) & 255u;
+      const uint64_t q = R.q0 + 4 * lane + j;
+      if (j == jx) { fb = l ? (f > q ? f : q) + l : f; break; }
+      if (l) f = (f > q ? f : q) + l;
+    }
+    *behind = __shfl(fb, (int)owner);
+    return __shfl(f, (int)owner);
+  };
+  // first empty slot >= x
+  auto first_empty = [&](uint64_t x) -> uint64_t {
+    for (uint64_t r = x >> SHK_REGION_LOG2;; r++) {
+      if (r >= nregions) { const uint64_t fe = fin[nregions]; return fe > x ? fe : x; }
+      const ShkVRegion R = shk_vregion(fin, lens, nslots, r, lane);
+      uint64_t f = R.fpre, found = ~0ULL;
+#pragma unroll
+      for (unsigned j = 0; j < 4; j++) {
+        const uint32_t l = (R.l4 >> (8 * j)) & 255u;
+        const uint64_t q = R.q0 + 4 * lane + j;
+        if (l) f = (f > q ? f : q) + l;                 // pointer behind quotient q
+        if (q >= x && f <= q && found == ~0ULL) found = q;
+      }
+      const unsigned long long m = __ballot(found != ~0ULL);
+      if (m) return __shfl(found, __ffsll((long long)m) - 1);
+      if (x < R.q0 + SHK_REGION) x = R.q0 + SHK_REGION;
+    }
+  };
+  // next quotient >= x that has a run; xnslots when there is none
+  auto first_nonempty = [&](uint64_t x) -> uint64_t {
+    for (uint64_t r = x >> SHK_REGION_LOG2; r < nregions; r++) {
+      const uint64_t q0 = r << SHK_REGION_LOG2;
+      if (isum[2 * r] != 0) {
+        const uint64_t myq = q0 + 4 * lane;
+        const uint32_t l4 = myq < nslots ? reinterpret_cast<const uint32_t *>(lens + q0)[lane] : 0u;
+        uint64_t found = ~0ULL;
+#pragma unroll
+        for (unsigned j = 0; j < 4; j++)
+          if (((l4 >> (8 * j)) & 255u) && myq + j >= x && found == ~0ULL) found = myq + j;
+        const unsigned long long m = __ballot(found != ~0ULL);
+        if (m) return __shfl(found, __ffsll((long long)m) - 1);
+      }
+    }
+    return xnslots;
+  };
+  unsigned long long n = 0;
+  uint64_t cur = first_nonempty(0);
+  while (cur < nslots) {
+    uint64_t end = cur + min_len > nslots ? nslots : cur + min_len;
+    end = first_empty(end) - 1;
+    // one-slot cluster exactly at `end`: slot end in use, slot end - 1 empty
+    uint64_t f1;
+    const uint64_t f0 = fp_at(end, &f1);
+    const bool used = f1 > end;
+    const bool prev_empty = end == 0 || f0 <= end - 1;
+    if (used && prev_empty) {
+      if (n < cap && lane == 0) prot[n] = end;
+      n++;
+    }
+    cur = first_nonempty(end + 1);
+  }
+  if (lane == 0) *nprot = n;
 }
 
 // ---------------------------------------------------------------- lookups

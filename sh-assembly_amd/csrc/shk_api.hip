@@ -26,12 +26,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -99,6 +99,8 @@ struct shk_ctx {
   uint32_t last_err_bits;
   double new_frac;              // new distinct keys per presented k-mer in the last committed range (predicts crossings)
   int staged;                   // which d_words[] holds the partitioned words of shk_stage_words
+  // one-pass deNoise point (denoise_fused): the intermediate table's (T, c), run lengths and free pointers; protected quotients
+  uint32_t *d_isum; uint8_t *d_ilens; uint64_t *d_fin_i; uint64_t *d_prot;
   int counted;                  // 1 while shk_insert_counted runs: the words' chunk field is a multiplicity
   uint64_t *d_send[2];          // shk_route_words: two alternating send buffers (allocated on first use), so that the
   int send_next;                // exchange of one batch can run while the next batch is hashed and routed
@@ -287,6 +289,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_block_sums);
   hipFree(c->d_base[0]);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
+  if (c->d_isum) { hipFree(c->d_isum); hipFree(c->d_ilens); hipFree(c->d_fin_i); hipFree(c->d_prot); }
   hipFree(c->d_spill); hipFree(c->d_over_list); if (c->d_newchunks) { hipFree(c->d_newchunks); hipFree(c->d_chist); hipHostFree(c->h_chist); } hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
   hipHostFree(c->h_pinned);
   hipStreamDestroy(c->stream);
@@ -450,6 +453,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->newchunks = nullptr;
   A->counted = c->counted;
   A->r0 = 0;
+  A->split = ~0u; A->isum = nullptr; A->ilens = nullptr; A->prot_list = nullptr; A->nprot = 0;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
 }
 
@@ -622,6 +626,103 @@ static int denoise_with_rest(shk_ctx *c, const uint64_t *words, uint32_t lo, uin
   return SHK_OK;
 }
 
+// ONE pass for a deNoise point inside a batch (the three-pass form: rebuild the chunks up to the point, mark, fused round +
+// rest). The hash keeps two counts per key -- occurrences in the chunks <= cstar and behind it -- so a lane knows every
+// key's count at the moment the round runs (cb) and what arrives afterwards (ca): the entry survives with cb when cb >= 2,
+// is dropped when cb == 1, and ca is added on top. What the round's range walk needs of the table in between (which never
+// exists in memory) leaves the same pass as 8 bytes + 256 length bytes per region; k_denoise_marks_virtual walks those.
+// The few singletons the walk protects (one-slot clusters on a range end) are put back by rebuilding their regions with
+// the list. Anything unusual (long runs, a cluster beyond the LDS image, a second crossing inside the rest) -> *done =
+// false and the caller takes the three-pass path.
+#define SHK_PROT_CAP 65536u
+static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t cstar, uint32_t hi, uint64_t newd_before,
+                         shk_batch_stats *st, bool *done) {
+  *done = false;
+  if (!c->use_spill || c->big_image || c->single_ok || getenv("SHK_NO_FUSED_POINT")) return SHK_OK;
+  if (!c->d_isum) {
+    if (dmalloc(&c->d_isum, 2 * (uint64_t)c->nregions + 2) || dmalloc(&c->d_ilens, (uint64_t)c->nregions * SHK_REGION) ||
+        dmalloc(&c->d_fin_i, (uint64_t)c->nregions + 2) || dmalloc(&c->d_prot, (uint64_t)SHK_PROT_CAP)) return SHK_ERR_HIP;
+  }
+  const uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
+  const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
+  const uint32_t img_slots = (uint32_t)SHK_IMG_SLOTS;
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
+  A.split = cstar; A.isum = c->d_isum; A.ilens = c->d_ilens;
+  c->spill_valid = 0;
+  uint64_t nprot = 0;
+  std::vector<uint64_t> prot;
+  for (int go = 0; go < 2; go++) {
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
+    { ProfScope ps(c, go == 0 ? KP_MERGE_FUSED : KP_MISC);
+      if (go == 0) {
+        SHK_FOR_REGION_SLICES(c, A, nblk)
+          hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
+        A.r0 = 0;
+      } else {
+        // the regions that hold a protected singleton, once more with the list
+        std::vector<uint32_t> regs;
+        for (uint64_t q : prot) { const uint32_t r = (uint32_t)(q >> SHK_REGION_LOG2); if (regs.empty() || regs.back() != r) regs.push_back(r); }
+        HIPCHK(hipMemcpyAsync(c->d_over_list, regs.data(), regs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        A.list = c->d_over_list; A.prot_list = c->d_prot; A.nprot = (uint32_t)nprot;
+        hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3((uint32_t)regs.size()), dim3(c->merge_group), 0, c->stream, A);
+        HIPCHK(hipStreamSynchronize(c->stream));   // (regs lives on this stack frame)
+      } }
+    { ProfScope ps(c, KP_REGION_SCAN);
+      hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b, (uint32_t)SHK_SUM_STRIDE);
+      hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
+      hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
+                         c->xnslots, img_slots, c->fin[c->cur ^ 1], c->d_counters, c->d_err, (uint32_t)SHK_SUM_STRIDE);
+      if (go == 0) {
+        // the table in between: free pointers at the region starts (its capacity flags count like the final table's)
+        hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_a, c->d_tile_b, 2u);
+        hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
+        hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_f,
+                           c->xnslots, img_slots, c->d_fin_i, c->d_counters, c->d_err, 2u);
+      } }
+    if (go == 0) {
+      ProfScope ps(c, KP_MARKS);
+      hipLaunchKernelGGL(k_denoise_marks_virtual, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->d_fin_i, (const uint8_t *)c->d_ilens,
+                         (const uint32_t *)c->d_isum, c->nslots, c->xnslots, ml, c->d_prot, SHK_PROT_CAP, (unsigned long long *)(c->d_scalars + 3));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+    if (go == 0) HIPCHK(hipMemcpyAsync(c->h_pinned + 47, c->d_scalars + 3, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t err = *(uint32_t *)(c->h_pinned + 40);
+    if (err) {                                   // not this way: nothing was committed
+      HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+      if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED fallback: flags 0x%x (go %d)\n", err, go);
+      return SHK_OK;
+    }
+    if (go == 0) {
+      nprot = c->h_pinned[47];
+      if (nprot > SHK_PROT_CAP) return SHK_OK;
+      if (nprot == 0) break;
+      prot.resize(nprot);
+      HIPCHK(hipMemcpyAsync(prot.data(), c->d_prot, nprot * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+  }
+  const uint64_t newd_after = c->h_pinned[0], added_after = c->h_pinned[1], removed = c->h_pinned[2], added_before = c->h_pinned[3];
+  // would the trigger be reached again inside the rest? then the rounds have to be taken one by one
+  if (c->rounds_left > 1 && c->ndistinct + newd_before - removed + newd_after >= c->cfg.ndistinct_for_denoise) return SHK_OK;
+  c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = 1; c->spill_big = c->big_image;
+  c->spill_nover = 0;
+  int rc = merge_write(c, words, lo, hi, 1);
+  if (rc) return rc;
+  c->nelts = c->nelts + added_before - removed + added_after;      // inserts, CQF_mt.h:1037-1038, inserts
+  c->ndistinct = c->ndistinct + newd_before - removed + newd_after;
+  c->rounds_left--; c->rounds_done++;
+  st->removed += removed; st->denoise_rounds++;
+  st->kmers += added_before + added_after; st->new_distinct += newd_before + newd_after; st->chunks += hi - lo + 1;
+  *done = true;
+  if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED one-pass point at chunk %u of [%u, %u]: removed %llu protected %llu\n", cstar, lo, hi,
+                                         (unsigned long long)removed, (unsigned long long)nprot);
+  return SHK_OK;
+}
+
 static int denoise_round(shk_ctx *c, uint64_t *removed) {
   int rc = denoise_round_once(c, removed);
   if (rc == SHK_ERR_REGION && !c->big_image && (c->last_err_bits & (SHK_E_OLD_EXTENT | SHK_E_NEW_EXTENT))) {
@@ -718,6 +819,14 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
         for (; ch < hi; ch++) {
           run += c->h_chist[ch];
           if (run >= c->cfg.ndistinct_for_denoise) break;
+        }
+        if (ch == hi) run += c->h_chist[ch];      // (the loop leaves the last chunk's keys out)
+        if (ch + 1 < nchunks) {
+          // the point lies inside the batch: everything -- the chunks up to it, the round, the chunks behind it -- in one pass
+          bool fused = false;
+          rc = denoise_fused(c, words, lo, ch, nchunks - 1, run - c->ndistinct, st, &fused);
+          if (rc) return rc;
+          if (fused) { lo = nchunks; continue; }
         }
         hi = ch;
       } else
