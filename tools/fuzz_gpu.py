@@ -46,13 +46,16 @@ def main():
         if q.full():
             q.free()
             continue
+        mlb = rnd.choice([0, 0, 2, 3, 4])      # partition levels of 2-4 bits: several levels on small filters
+        if mlb and (qb - 8 + mlb - 1) // mlb > 4:
+            mlb = (qb - 8 + 3) // 4             # (at most four levels)
         if args.sharded:
             ctx = shk.Context(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L + 64,
-                              shard_index=0, num_shards=1)
+                              shard_index=0, num_shards=1, max_level_bits=mlb)
             sst = shkdist.ShardState(trig, nd, dev)
         else:
             ctx = shk.Context(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024,
-                              max_batch_keys=nreads * L + 64)
+                              max_batch_keys=nreads * L + 64, max_level_bits=mlb)
         ncalls = rnd.choice([1, 2, 3, len(offs)])
         step = max(1, (len(offs) + ncalls - 1) // ncalls)
         rounds = removed = 0
