@@ -320,7 +320,7 @@ def main():
         traffic, traffic_src, step_traffic = None, None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            pk = {"k_region_merge<spill>": "k_region_merge<3, 24>", "k_region_place": "k_region_place<24>"}.get(name, name)
+            pk = {"k_region_merge<spill>": "k_region_merge<3, 24, false>", "k_region_place": "k_region_place<24>"}.get(name, name)
             if default_workload and pk in pt["kernels"]:
                 traffic = pt["kernels"][pk]["fetch_bytes_per_launch"] + pt["kernels"][pk]["write_bytes_per_launch"]
                 traffic_src = pt["source"]

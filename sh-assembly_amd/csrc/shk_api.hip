@@ -1623,8 +1623,11 @@ extern "C" int shk_extend_forward(shk_ctx *c, const char *cur_kmers, const char 
   HIPCHK(hipMemcpyAsync(w.dk, cur_kmers, nk, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(w.df, first_kmers, nk, hipMemcpyHostToDevice, c->stream));
   { ProfScope ps(c, KP_WALK);
+    char *dk = w.dk, *df = w.df, *db = w.db;          // (plain pointers: the launch must not capture the owning struct)
+    uint32_t *dc = w.dc, *dn = w.dn, *dnc = w.dnc;
+    uint8_t *ds = w.ds, *dbr = w.dbr;
     hipLaunchKernelGGL(k_extend_forward, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->tab[c->cur], c->q_lo, c->nslots,
-                       c->cfg.hb, w.dk, w.df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, w.db, w.dc, w.dn, w.ds, w.dbr, w.dnc); }
+                       c->cfg.hb, dk, df, n, k, abundance_min, mark_traveled ? 1 : 2, max_ext, db, dc, dn, ds, dbr, dnc); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_bases, w.db, ne, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(out_counts, w.dc, ne * 4, hipMemcpyDeviceToHost, c->stream));
