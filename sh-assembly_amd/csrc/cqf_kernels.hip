@@ -63,6 +63,7 @@ struct ShkMergeArgs {
   uint32_t nprot;
   uint32_t r0;                    // first region of this launch (a pass over more than 2^24 regions takes several launches:
                                   // HIP limits a grid to fewer than 2^32 threads)
+  uint32_t rstride;               // region = (blockIdx.x + r0) * rstride: > 1 for the statistics pass over a sample of the regions
   int counted;                    // 1: the records' chunk field holds (multiplicity - 1) of a counted insert (insert_advance with
                                   // count > 1, gqf.c:2024-2136); every record takes part, no chunk statistics
 };
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   const unsigned tid = threadIdx.x;
   const unsigned ngrp = blockDim.x;              // all waves of the group: staging, init, key folding
   constexpr unsigned nthr = SHK_MERGE_THREADS;   // one wave does the rest
-  const uint32_t r = A.list ? A.list[blockIdx.x] : blockIdx.x + A.r0;
+  const uint32_t r = A.list ? A.list[blockIdx.x] : (blockIdx.x + A.r0) * A.rstride;
   const uint32_t nregions = (uint32_t)((A.nslots + SHK_REGION - 1) / SHK_REGION);
   const uint64_t q0 = (uint64_t)r * SHK_REGION;
   const uint32_t nq = (uint32_t)((A.nslots - q0) < SHK_REGION ? (A.nslots - q0) : SHK_REGION);
@@ -533,6 +534,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
         }
         if (take_new) {
           cb += hcnt[nh]; ca = hcntB[nh];
+          if (A.newchunks && !take_old) hcnt[nh] |= 0x80000000u;   // a key the table has not seen: its first chunk is collected below
           ni++;
           ncomp = NONE;
           if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
@@ -677,6 +679,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       sm[0] = fatal ? 0 : (uint32_t)tot.a;
       sm[1] = (!fatal && tot.b > 0) ? (uint32_t)tot.b : 0;
       sm[2] = t_new; sm[3] = t_added; sm[4] = t_removed; sm[5] = t_before;
+      if (!(A.want_hist && A.newchunks && !fatal)) sm[7] = 0;      // no first-chunk record of this region
       if (tot.a > 0xFFFF) atomicOr(A.err, SHK_E_RUN_TOO_LONG);
       if (s_fail) atomicOr(A.err, s_fail);
     }
@@ -695,6 +698,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       if (f) nc[base + (uint32_t)__popcll(m & ((1ULL << tid) - 1))] = (uint16_t)(hkey[h] & (SHK_MAX_CHUNKS - 1));
       base += (uint32_t)__popcll(m);
     }
+    if (tid == 0) A.summary[(size_t)SHK_SUM_STRIDE * r + 7] = base;   // entries of this region's record (k_chunk_hist)
   }
   if (MODE == 3) {
     // spill: 4 length bytes per lane, then the lanes' staged bytes back to back
@@ -1002,16 +1006,17 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
 
 // exact histogram of first chunks over all regions (input: newchunks + the regions' new-key counts)
 #define SHK_CHIST_REGIONS 2048   // regions per workgroup
-__global__ void k_chunk_hist(const uint16_t *newchunks, const uint32_t *summary, uint32_t nregions, unsigned long long *chist) {
+__global__ void k_chunk_hist(const uint16_t *newchunks, const uint32_t *summary, uint32_t nregions, unsigned long long *chist,
+                             uint32_t rstride = 1) {
   __shared__ uint32_t lh[SHK_MAX_CHUNKS];
   for (uint32_t i = threadIdx.x; i < SHK_MAX_CHUNKS; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   const uint32_t lane = shk_lane(), wave = shk_wave(), nw = blockDim.x / SHK_WAVE;
   const uint32_t r0 = blockIdx.x * SHK_CHIST_REGIONS;
   for (uint32_t i = wave; i < SHK_CHIST_REGIONS; i += nw) {
-    const uint32_t r = r0 + i;
-    if (r >= nregions) break;
-    const uint32_t n = summary[(size_t)SHK_SUM_STRIDE * r + 2];
+    if ((uint64_t)(r0 + i) * rstride >= nregions) break;
+    const uint32_t r = (r0 + i) * rstride;                    // (rstride > 1: the sampled statistics pass)
+    const uint32_t n = summary[(size_t)SHK_SUM_STRIDE * r + 7];
     const uint16_t *nc = newchunks + (size_t)r * SHK_HCAP;
     for (uint32_t j = lane; j < n && j < SHK_HCAP; j += SHK_WAVE) atomicAdd(&lh[nc[j]], 1u);
   }

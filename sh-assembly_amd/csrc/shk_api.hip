@@ -26,12 +26,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -86,6 +86,7 @@ struct shk_ctx {
   unsigned long long *d_chist;  // [SHK_MAX_CHUNKS]
   uint64_t *h_chist;            // pinned
   uint32_t chist_n;             // entries of h_chist valid from the last summary (0 = none)
+  uint32_t sample_stride;       // sampled statistics pass before a deNoise point: every n-th region (<= 1: off)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -249,6 +250,10 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->merge_group = SHK_MERGE_GROUP;
   if (const char *mg = getenv("SHK_MERGE_GROUP")) { int v = atoi(mg); if (v == 64 || v == 128) c->merge_group = (uint32_t)v; }
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
+  // the sampled location of a deNoise point needs enough regions for the sample to mean something
+  c->sample_stride = 8;
+  if (const char *e = getenv("SHK_SAMPLE_STRIDE")) c->sample_stride = (uint32_t)atoi(e);
+  else if (c->nregions < (1u << 14)) c->sample_stride = 0;
   if (dmalloc(&c->d_spill, (uint64_t)c->nregions * SHK_SPILL_STRIDE) || dmalloc(&c->d_over_list, (uint64_t)c->nregions + 1)) return SHK_ERR_HIP;
   { uint64_t nt = c->nregions / SHK_RSCAN_TILE + 2;
     if (dmalloc(&c->d_tile_a, nt) || dmalloc(&c->d_tile_b, nt) || dmalloc(&c->d_tile_f, nt)) return SHK_ERR_HIP; }
@@ -452,9 +457,17 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
   A->newchunks = nullptr;
   A->counted = c->counted;
-  A->r0 = 0;
+  A->r0 = 0; A->rstride = 1;
   A->split = ~0u; A->isum = nullptr; A->ilens = nullptr; A->prot_list = nullptr; A->nprot = 0;
   A->summary = c->d_summary; A->counters = c->d_counters; A->hist = c->d_counters + 4; A->err = c->d_err;
+}
+
+// first request for the exact first-chunk histogram (contexts that never reach a deNoise point never pay for it)
+static int ensure_chist(shk_ctx *c) {
+  if (c->d_newchunks) return SHK_OK;
+  if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
+  HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
+  return SHK_OK;
 }
 
 // summary launch + free-pointer scan, then read the statistics back (one synchronisation)
@@ -465,11 +478,7 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
   spill = spill && c->use_spill;
   c->spill_valid = 0;
-  if (want_hist == 2 && !c->d_newchunks && !getenv("SHK_COARSE_HIST")) {
-    // first request for the exact histogram (contexts that never reach a deNoise point never pay for it)
-    if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
-    HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
-  }
+  if (want_hist == 2 && !getenv("SHK_COARSE_HIST")) { int rc = ensure_chist(c); if (rc) return rc; }
   const bool exact = want_hist == 2 && c->d_newchunks;
   if (exact) A.newchunks = c->d_newchunks;
   o->have_chist = 0;
@@ -635,10 +644,15 @@ static int denoise_with_rest(shk_ctx *c, const uint64_t *words, uint32_t lo, uin
 // the list. Anything unusual (long runs, a cluster beyond the LDS image, a second crossing inside the rest) -> *done =
 // false and the caller takes the three-pass path.
 #define SHK_PROT_CAP 65536u
+// verify: cstar is a GUESS (sample_locate). The pass then also records the first chunk of every key the table has not seen,
+// like the plain pass does; if the exact histogram puts the point at cstar the pass stands, otherwise nothing is committed
+// and *exact_ch / *crossing (1: the trigger is reached at chunk *exact_ch, 0: not reached in [lo, hi]) say what is true.
 static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t cstar, uint32_t hi, uint64_t newd_before,
-                         shk_batch_stats *st, bool *done) {
+                         shk_batch_stats *st, bool *done, bool verify = false, uint32_t *exact_ch = nullptr, int *crossing = nullptr) {
   *done = false;
+  if (crossing) *crossing = -1;
   if (!c->use_spill || c->big_image || c->single_ok || getenv("SHK_NO_FUSED_POINT")) return SHK_OK;
+  if (verify) { int rc = ensure_chist(c); if (rc) return rc; }
   if (!c->d_isum) {
     if (dmalloc(&c->d_isum, 2 * (uint64_t)c->nregions + 2) || dmalloc(&c->d_ilens, (uint64_t)c->nregions * SHK_REGION) ||
         dmalloc(&c->d_fin_i, (uint64_t)c->nregions + 2) || dmalloc(&c->d_prot, (uint64_t)SHK_PROT_CAP)) return SHK_ERR_HIP;
@@ -649,7 +663,9 @@ static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
   A.split = cstar; A.isum = c->d_isum; A.ilens = c->d_ilens;
+  if (verify) { A.want_hist = 2; A.newchunks = c->d_newchunks; }
   c->spill_valid = 0;
+  c->chist_n = 0;
   uint64_t nprot = 0;
   std::vector<uint64_t> prot;
   for (int go = 0; go < 2; go++) {
@@ -665,6 +681,7 @@ static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
         for (uint64_t q : prot) { const uint32_t r = (uint32_t)(q >> SHK_REGION_LOG2); if (regs.empty() || regs.back() != r) regs.push_back(r); }
         HIPCHK(hipMemcpyAsync(c->d_over_list, regs.data(), regs.size() * 4, hipMemcpyHostToDevice, c->stream));
         A.list = c->d_over_list; A.prot_list = c->d_prot; A.nprot = (uint32_t)nprot;
+        A.want_hist = 0; A.newchunks = nullptr;
         hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3((uint32_t)regs.size()), dim3(c->merge_group), 0, c->stream, A);
         HIPCHK(hipStreamSynchronize(c->stream));   // (regs lives on this stack frame)
       } }
@@ -680,6 +697,13 @@ static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
         hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_f,
                            c->xnslots, img_slots, c->d_fin_i, c->d_counters, c->d_err, 2u);
       } }
+    if (go == 0 && verify) {
+      ProfScope ps(c, KP_MISC);
+      HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+      hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
+                         c->d_newchunks, c->d_summary, c->nregions, c->d_chist, 1u);
+      HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     if (go == 0) {
       ProfScope ps(c, KP_MARKS);
       hipLaunchKernelGGL(k_denoise_marks_virtual, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->d_fin_i, (const uint8_t *)c->d_ilens,
@@ -695,6 +719,23 @@ static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
       HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
       if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED fallback: flags 0x%x (go %d)\n", err, go);
       return SHK_OK;
+    }
+    if (go == 0 && verify) {
+      // where the running distinct count really reaches the trigger (the loop of merge_stage_from)
+      uint64_t run = c->ndistinct;
+      uint32_t ch = lo;
+      for (; ch < hi; ch++) {
+        run += c->h_chist[ch];
+        if (run >= c->cfg.ndistinct_for_denoise) break;
+      }
+      if (ch == hi) run += c->h_chist[ch];
+      const bool crosses = run >= c->cfg.ndistinct_for_denoise;
+      c->chist_n = hi + 1;
+      if (exact_ch) *exact_ch = ch;
+      if (crossing) *crossing = crosses ? 1 : 0;
+      if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED guess %u exact %u crossing %d\n", cstar, ch, (int)crosses);
+      if (!crosses || ch != cstar) return SHK_OK;
+      newd_before = run - c->ndistinct;
     }
     if (go == 0) {
       nprot = c->h_pinned[47];
@@ -734,6 +775,56 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
   return rc;
 }
 
+// Where will the deNoise point of this batch fall? A statistics pass over every sample_stride-th region with the exact
+// first-chunk record, scaled up: regions are hash buckets, so the sample's per-chunk counts of new keys are the whole
+// table's divided by the stride, up to Poisson noise (variance of the scaled sum = stride x sum). The answer is only a
+// guess -- the one-pass point that is run with it checks it against the full histogram it produces itself.
+// verdict 0: no point expected in [lo, hi]; 1: expected at chunk *guess; 2: cannot tell
+static int sample_locate(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int *verdict, uint32_t *guess) {
+  *verdict = 2;
+  if (c->ndistinct >= c->cfg.ndistinct_for_denoise) return SHK_OK;
+  int rc = ensure_chist(c);
+  if (rc) return rc;
+  const uint32_t stride = c->sample_stride;
+  const uint32_t ns = (c->nregions + stride - 1) / stride;
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, lo, 0, 0, 2);
+  A.newchunks = c->d_newchunks; A.rstride = stride;
+  c->spill_valid = 0;
+  c->chist_n = 0;
+  { ProfScope ps(c, KP_MERGE_SAMPLE);
+    for (uint32_t r0 = 0; r0 < ns; r0 += SHK_REGION_SLICE) {
+      A.r0 = r0;
+      const uint32_t nblk = ns - r0 < SHK_REGION_SLICE ? ns - r0 : SHK_REGION_SLICE;
+      hipLaunchKernelGGL((k_region_merge<0, SHK_IMG_BLOCKS>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
+    }
+    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+    hipLaunchKernelGGL(k_chunk_hist, dim3((ns + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
+                       c->d_newchunks, c->d_summary, c->nregions, c->d_chist, stride); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const uint32_t err = *(uint32_t *)(c->h_pinned + 40);
+  if (err) {                       // whatever it is, the full pass will meet it again and deal with it
+    HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+    return SHK_OK;
+  }
+  const double F = (double)c->nregions / (double)ns;
+  const double need = (double)(c->cfg.ndistinct_for_denoise - c->ndistinct);
+  double cum = 0;
+  uint32_t at = hi + 1;
+  for (uint32_t ch = lo; ch <= hi; ch++) {
+    cum += F * (double)c->h_chist[ch];
+    if (at > hi && cum >= need) at = ch;
+  }
+  const double margin = 6.0 * sqrt(F * cum + 1.0);
+  if (cum + margin < need) *verdict = 0;
+  else if (cum - margin >= need && at <= hi) { *verdict = 1; *guess = at; }
+  if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED sample: need %.0f predicted %.0f +- %.0f -> verdict %d at %u of [%u, %u]\n", need, cum, margin / 6.0, *verdict, at, lo, hi);
+  return SHK_OK;
+}
+
 // Insert the words of chunks [0, nchunks) (already partitioned in `words`), firing deNoise
 // rounds where the t = 1 reference would: after the first chunk at which
 // ndistinct >= trigger while rounds are left (CQF_mt.h:837, 860-869).
@@ -766,6 +857,30 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
     // point that is missed this way only costs one more statistics pass)
     const double reach = c->new_frac > 0 ? 2.0 * c->new_frac * (double)nwords * (double)(hi - lo + 1) / (double)nchunks : (double)nwords;
     const bool possible = watch && (double)c->ndistinct + reach >= (double)c->cfg.ndistinct_for_denoise;
+    int sv = 2;
+    if (possible && c->sample_stride > 1 && c->use_spill && !c->single_ok && !c->big_image && !c->counted) {
+      // guess the chunk of the deNoise point from a sample of the regions and run the one-pass point with it; the pass
+      // verifies the guess against the exact histogram it collects itself and, when it was wrong, is run once more
+      uint32_t guess = 0;
+      rc = sample_locate(c, words, lo, hi, &sv, &guess);
+      if (rc) return rc;
+      if (sv == 1 && guess + 1 < nchunks) {
+        bool fused = false;
+        uint32_t ech = 0;
+        int crossing = -1;
+        rc = denoise_fused(c, words, lo, guess, nchunks - 1, 0, st, &fused, true, &ech, &crossing);
+        if (rc) return rc;
+        if (fused) { lo = nchunks; continue; }
+        if (crossing == 1 && ech != guess && ech + 1 < nchunks) {
+          uint64_t run = 0;
+          for (uint32_t ch = lo; ch <= ech; ch++) run += c->h_chist[ch];
+          rc = denoise_fused(c, words, lo, ech, nchunks - 1, run, st, &fused);
+          if (rc) return rc;
+          if (fused) { lo = nchunks; continue; }
+        }
+        // (anything else: the general path below)
+      }
+    }
     if (c->single_ok && !likely) {
       // single-launch scheme: one launch does statistics and table
       rc = merge_single(c, words, lo, hi, 0, &o, possible ? 1 : 0, lo, shift);
@@ -789,7 +904,7 @@ static int merge_stage_from(shk_ctx *c, const uint64_t *words, uint32_t nchunks,
       uint32_t span = hi - lo + 1;
       shift = 0;
       while ((span + (1u << shift) - 1) >> shift > SHK_HIST_BINS) shift++;
-      const int wh = (likely || (possible && c->use_spill)) ? 2 : 0;
+      const int wh = sv == 0 ? 0 : ((likely || (possible && c->use_spill)) ? 2 : 0);   // (sv == 0: the sample rules a point out)
       rc = merge_summary(c, words, lo, hi, lo, shift, 0, &o, wh, 1);
       if (rc) return rc;
       if (wh && !(o.err & ~soft)) have_hist = true;

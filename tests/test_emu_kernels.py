@@ -51,9 +51,12 @@ def test_key_stream_is_reference_order(shk):
         ctx.close()
 
 
-def test_count_and_denoise_schedule(shk):
+@pytest.mark.parametrize("stride", ["0", "2"])
+def test_count_and_denoise_schedule(shk, monkeypatch, stride):
     """hash -> partition (several levels forced) -> merge -> deNoise rounds where the t = 1 schedule
-    fires them; table bytes, header and counters equal the oracle's"""
+    fires them; table bytes, header and counters equal the oracle's. stride 2: the chunk of a deNoise point is first
+    guessed from a statistics pass over every second region and the one-pass point verifies the guess (sample_locate)"""
+    monkeypatch.setenv("SHK_SAMPLE_STRIDE", stride)
     fq = synth.make_fastq(synth.make_genome(300, 7), 32, 90, 0.01, seed=21, n_frac=0.05, short_frac=0.03)
     offs, lens = chunks_by_records(fq, 4)
     qb, k, trig, nd, ml = 10, 28, 350, 3, 64

@@ -49,6 +49,9 @@ def main():
         mlb = rnd.choice([0, 0, 2, 3, 4])      # partition levels of 2-4 bits: several levels on small filters
         if mlb and (qb - 8 + mlb - 1) // mlb > 4:
             mlb = (qb - 8 + 3) // 4             # (at most four levels)
+        # sampled location of the deNoise point (read at context creation): off, or every 2nd / 4th / 8th region -- on these
+        # small tables the guess is often wrong, which is the point
+        os.environ["SHK_SAMPLE_STRIDE"] = str(rnd.choice([0, 2, 2, 4, 8]))
         if args.sharded:
             ctx = shk.Context(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L + 64,
                               shard_index=0, num_shards=1, max_level_bits=mlb)
