@@ -256,14 +256,27 @@ def main():
                 # pipelined: the all-to-all of batch s was started one step ago; before waiting for it, batch s+1 is
                 # hashed, binned by owner (second send buffer) and ITS exchange started -- xGMI moves key words while
                 # the CUs stage and insert batch s
+                tm = [time.perf_counter()]
+
+                def lap():          # diagnostics (--trace): where a sharded step spends its time
+                    if args.trace:
+                        torch.cuda.synchronize()
+                        tm.append(time.perf_counter())
                 if s not in self.inflight:
                     self.inflight[s] = self.exchange(s)
                 ex = self.inflight.pop(s)
                 if s + 1 < nsteps:
                     self.inflight[s + 1] = self.exchange(s + 1)
+                lap()
                 recv = ex.wait()
+                lap()
                 ctx.stage_words(recv.data_ptr(), recv.numel())
+                lap()
                 st = shkdist.sharded_count(ctx, self.sstate, len(offs) * world)   # counts are whole-job (all-reduced)
+                lap()
+                if args.trace and rank == 0:
+                    print("step %d: hash+route+start exchange %.1f ms, wait %.1f ms, stage %.1f ms, count %.1f ms (%d collectives so far)" % (
+                        (s,) + tuple(1e3 * (tm[i + 1] - tm[i]) for i in range(4)) + (self.sstate.collectives,)), file=sys.stderr, flush=True)
                 if s + 1 == nsteps:
                     shkdist.check(ctx, self.sstate)
             self.counted += st["kmers"]

@@ -179,6 +179,40 @@ int shk_stage_try_denoise(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, sh
  * (The first want_hist = 2 pass allocates nregions KiB of device memory for the first-chunk records.) */
 int shk_stage_chunk_hist(shk_ctx *ctx, uint64_t *out, uint32_t n);
 
+/* ---- a deNoise point inside the staged batch in ONE rebuild per shard (the sharded form of what shk_count_chunks does
+ * on a single table; replaces try(lo..point) + accept + try_denoise + accept). The ranks take the steps together
+ * (sh-assembly_amd/shk/dist.py: _one_pass_point); nothing is written before shk_stage_accept.
+ *   shk_stage_sample        statistics pass over every n-th region: hist[i] = keys new to the filter first seen in chunk
+ *                           i, within the sample (i <= chunk_hi); summed over the shards and scaled by regions / sampled
+ *                           it predicts the chunk at which the filter-wide distinct count reaches the trigger
+ *   shk_stage_point_try     the rebuild with two counts per key (chunks <= split / behind it): entries whose count at the
+ *                           split is 1 are dropped (qf_remove_singletons as run by CQF_mt.h:860-869 after chunk `split`),
+ *                           the later chunks added on top. Also records the exact first-chunk histogram
+ *                           (shk_stage_chunk_hist) with which the ranks check that `split` IS the chunk of the point.
+ *                           out->islots / ifin / first_used describe the shard's table at the split (slots in use, free
+ *                           pointer behind its last quotient, run on quotient 0): what the next shard needs to lay its
+ *                           own part out as in the single table
+ *   shk_stage_point_walk    the round's range walk (CQF_mt.h:888-895) over this shard, continuing the previous shard's:
+ *                           carry = slots the earlier shards spill over this shard's first quotient (>= 0), prev_fp = their
+ *                           free pointer relative to it (negative when they end before it; -1 for shard 0), state_in/out
+ *                           = {0, 0} between two ranges / {1, minimum end of the open range relative to the next shard};
+ *                           *nprot singletons on range ends survive the round (kept on the device for _finish)
+ *   shk_stage_point_finish  rebuilds the regions holding those; `out` = final statistics, `accept` = what to hand to
+ *                           shk_stage_accept when every rank is clean and the trigger is not reached again in the rest */
+typedef struct shk_point {
+  uint64_t new_after, added_after;   /* keys new to the table after the round / occurrences from the chunks behind the split */
+  uint64_t removed, added_before;    /* singletons dropped / occurrences from the chunks up to the split */
+  uint64_t islots, ifin;
+  uint32_t first_used;
+  uint32_t err_bits;                 /* any bit: do not go on with this point (take the three-pass path) */
+} shk_point;
+int shk_stage_sample(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint64_t *hist, uint32_t *regions, uint32_t *sampled,
+                     uint32_t *err_bits);
+int shk_stage_point_try(shk_ctx *ctx, uint32_t chunk_lo, uint32_t split, uint32_t chunk_hi, shk_point *out);
+int shk_stage_point_walk(shk_ctx *ctx, int64_t carry, int64_t prev_fp, int last, int next_first_used, const uint64_t state_in[2],
+                         uint64_t state_out[2], uint64_t *nprot, uint32_t *err_bits);
+int shk_stage_point_finish(shk_ctx *ctx, shk_point *out, shk_summary *accept);
+
 /* One deNoise round now (the reference's --endDeNoise round; does not use up num_denoise). */
 int shk_denoise(shk_ctx *ctx, uint64_t *removed);
 

@@ -1063,10 +1063,12 @@ __global__ void k_region_scan_a(const uint32_t *summary, uint32_t nregions, long
   if (threadIdx.x == 0) { tile_a[blockIdx.x] = tot.a; tile_b[blockIdx.x] = tot.b; }
 }
 // b: one workgroup: free pointer at every tile start
-__global__ void k_region_scan_b(const long long *tile_a, const long long *tile_b, uint32_t ntiles, long long *tile_f) {
+// (f0: free pointer in front of the first region -- 0, or what the shards before this one spill over the border when the
+// layout of the whole filter is wanted)
+__global__ void k_region_scan_b(const long long *tile_a, const long long *tile_b, uint32_t ntiles, long long *tile_f, long long f0 = 0) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   __shared__ long long carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+  if (threadIdx.x == 0) carry_s = f0;
   __syncthreads();
   for (uint32_t b0 = 0; b0 < ntiles; b0 += blockDim.x) {
     const uint32_t t = b0 + threadIdx.x;
@@ -1095,15 +1097,21 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
   ShkMP tot;
   ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
   long long f = shk_mp_apply(pre, tile_f[blockIdx.x]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) fin[0] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) fin[0] = (uint64_t)tile_f[0];
+  uint64_t slots = 0;
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t r = r0 + j;
     if (r >= nregions) break;
     const ShkMP m = shk_region_mp(summary, r, nregions, stride);
     f = shk_mp_apply(m, f);
     fin[r + 1] = (uint64_t)f;
+    slots += (uint64_t)m.a;
     if (m.a > 0 && f - (long long)r * SHK_REGION > (long long)img_slots) atomicOr(err, SHK_E_NEW_EXTENT);
     if ((uint64_t)f > xnslots) atomicOr(err, SHK_E_TABLE_FULL);
+  }
+  if (stride == 2) {        // intermediate table of a one-pass deNoise point: slots in use (its shard's share of the free-pointer function)
+    const uint64_t t = shk_block_sum64(slots, scratch64);
+    if (threadIdx.x == 0 && t) atomicAdd(&counters[4 + SHK_HIST_BINS + 1], (unsigned long long)t);
   }
   // statistics of this tile's regions
   if (stride >= 6)
@@ -1278,9 +1286,22 @@ __device__ __forceinline__ ShkVRegion shk_vregion(const uint64_t *fin, const uin
   R.fpre = (uint64_t)shk_mp_apply(pre, (long long)fin[r]);
   return R;
 }
+// A filter sharded by quotient range is walked shard by shard (ShkWalkShard): fin is then laid out with the free pointer
+// the earlier shards carry over the border, so local coordinates + the shard's first quotient = coordinates of the single
+// table; a shard stops where it would have to look at slots of the next one and leaves the state of the walk behind:
+// state[0] = 0: between two ranges, the next one starts at the first run at or behind local slot state[1];
+// state[0] = 1: inside a range whose minimum end is local slot state[1] (of the NEXT shard when written, of this one when
+// read). The single table is the one-shard case (last = 1, state_in = {0, 0}).
+struct ShkWalkShard {
+  long long prev_fp;        // free pointer of everything in front of this shard, local (negative: ends before the border); shard 0: -1
+  uint64_t cap_local;       // slots from this shard's first to the end of the whole filter (range ends are capped there)
+  int last;                 // the filter ends with this shard
+  int next_first_used;      // quotient 0 of the next shard has a run (its slot is the first one behind this shard)
+};
 __global__ void __launch_bounds__(SHK_WAVE) k_denoise_marks_virtual(const uint64_t *fin, const uint8_t *lens, const uint32_t *isum, uint64_t nslots,
                                                                     uint64_t xnslots, uint64_t min_len, uint64_t *prot, uint32_t cap,
-                                                                    unsigned long long *nprot) {
+                                                                    unsigned long long *nprot, ShkWalkShard W, const uint64_t *state_in,
+                                                                    uint64_t *state_out) {
   if (blockIdx.x != 0) return;
   const unsigned lane = threadIdx.x & (SHK_WAVE - 1);
   const uint64_t nregions = (nslots + SHK_REGION - 1) / SHK_REGION;
@@ -1301,9 +1322,10 @@ __global__ void __launch_bounds__(SHK_WAVE) k_denoise_marks_virtual(const uint64
     return __shfl(f, (int)owner);
   };
   // first empty slot >= x
+  // (~0: every own slot from x on is in use -- the answer lies behind this shard)
   auto first_empty = [&](uint64_t x) -> uint64_t {
     for (uint64_t r = x >> SHK_REGION_LOG2;; r++) {
-      if (r >= nregions) { const uint64_t fe = fin[nregions]; return fe > x ? fe : x; }
+      if (r >= nregions) return ~0ULL;
       const ShkVRegion R = shk_vregion(fin, lens, nslots, r, lane);
       uint64_t f = R.fpre, found = ~0ULL;
 #pragma unroll
@@ -1311,7 +1333,7 @@ __global__ void __launch_bounds__(SHK_WAVE) k_denoise_marks_virtual(const uint64
         const uint32_t l = (R.l4 >> (8 * j)) & 255u;
         const uint64_t q = R.q0 + 4 * lane + j;
         if (l) f = (f > q ? f : q) + l;                 // pointer behind quotient q
-        if (q >= x && f <= q && found == ~0ULL) found = q;
+        if (q >= x && q < nslots && f <= q && found == ~0ULL) found = q;
       }
       const unsigned long long m = __ballot(found != ~0ULL);
       if (m) return __shfl(found, __ffsll((long long)m) - 1);
@@ -1336,22 +1358,39 @@ __global__ void __launch_bounds__(SHK_WAVE) k_denoise_marks_virtual(const uint64
     return xnslots;
   };
   unsigned long long n = 0;
-  uint64_t cur = first_nonempty(0);
-  while (cur < nslots) {
-    uint64_t end = cur + min_len > nslots ? nslots : cur + min_len;
-    end = first_empty(end) - 1;
+  uint64_t kind = state_in[0], x = state_in[1];
+  uint64_t out0 = 0, out1 = 0;
+  const bool boundary_used = fin[nregions] > nslots || W.next_first_used;     // the first slot behind this shard
+  for (;;) {
+    uint64_t end0;
+    if (kind == 0) {
+      const uint64_t cur = first_nonempty(x);
+      if (cur >= nslots) break;                       // no further range starts in this shard ({0, 0} for the next one)
+      end0 = cur + min_len > W.cap_local ? W.cap_local : cur + min_len;
+    } else end0 = x;
+    kind = 0;
+    uint64_t e;
+    if (!W.last && end0 > nslots) { out0 = 1; out1 = end0 - nslots; break; }
+    if (end0 >= nslots) e = ~0ULL;
+    else e = first_empty(end0);
+    if (e == ~0ULL) {
+      if (W.last) { const uint64_t fe = fin[nregions]; e = fe > end0 ? fe : end0; }
+      else if (boundary_used) { out0 = 1; out1 = 0; break; }
+      else e = nslots;
+    }
+    const uint64_t end = e - 1;
     // one-slot cluster exactly at `end`: slot end in use, slot end - 1 empty
     uint64_t f1;
     const uint64_t f0 = fp_at(end, &f1);
     const bool used = f1 > end;
-    const bool prev_empty = end == 0 || f0 <= end - 1;
+    const bool prev_empty = end == 0 ? W.prev_fp <= -1 : f0 <= end - 1;
     if (used && prev_empty) {
       if (n < cap && lane == 0) prot[n] = end;
       n++;
     }
-    cur = first_nonempty(end + 1);
+    x = end + 1;
   }
-  if (lane == 0) *nprot = n;
+  if (lane == 0) { *nprot = n; state_out[0] = out0; state_out[1] = out1; }
 }
 
 // ---------------------------------------------------------------- lookups

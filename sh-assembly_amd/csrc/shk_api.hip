@@ -87,6 +87,7 @@ struct shk_ctx {
   uint64_t *h_chist;            // pinned
   uint32_t chist_n;             // entries of h_chist valid from the last summary (0 = none)
   uint32_t sample_stride;       // sampled statistics pass before a deNoise point: every n-th region (<= 1: off)
+  uint32_t pt_lo, pt_split, pt_hi; int pt_valid; uint64_t pt_nprot;   // one-pass deNoise point in progress (shk_stage_point_*)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -453,7 +454,8 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
   A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
-  A->dbg = getenv("SHK_STAMPS") ? (unsigned long long *)(c->d_scalars + 16) : nullptr;
+  { const char *sp = getenv("SHK_STAMPS");    // diagnostics: "fused" = only the one-pass deNoise launches, "plain" = all the others, else all
+    A->dbg = (sp && strcmp(sp, "fused") != 0) ? (unsigned long long *)(c->d_scalars + 16) : nullptr; }
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
   A->newchunks = nullptr;
   A->counted = c->counted;
@@ -641,9 +643,146 @@ static int denoise_with_rest(shk_ctx *c, const uint64_t *words, uint32_t lo, uin
 // is dropped when cb == 1, and ca is added on top. What the round's range walk needs of the table in between (which never
 // exists in memory) leaves the same pass as 8 bytes + 256 length bytes per region; k_denoise_marks_virtual walks those.
 // The few singletons the walk protects (one-slot clusters on a range end) are put back by rebuilding their regions with
-// the list. Anything unusual (long runs, a cluster beyond the LDS image, a second crossing inside the rest) -> *done =
-// false and the caller takes the three-pass path.
+// the list. Anything unusual (long runs, a cluster beyond the LDS image, a second crossing inside the rest) -> the caller
+// takes the three-pass path.
+// Three steps, shared by the single-table flow (denoise_fused) and the sharded one (shk_stage_point_*):
+//   point_try    the FUSED pass over all regions + both free-pointer scans (+ the exact first-chunk histogram)
+//   point_walk   the range walk over the intermediate layout -> protected singletons of this table / shard
+//   point_finish their regions once more with the list; final statistics; the spill records are then ready for placement
 #define SHK_PROT_CAP 65536u
+struct PointOut {
+  uint64_t newd_after, added_after, removed, added_before;   // statistics (CQF_mt.h:1037-1038 bookkeeping)
+  uint32_t err;                                              // kernel flags: anything set = not this way
+  uint64_t islots, ifin;      // intermediate table: slots in use, free pointer behind the last region (local, carry 0)
+  int first_used;             // intermediate table: quotient 0 has a run
+};
+
+static int point_alloc(shk_ctx *c) {
+  if (c->d_isum) return SHK_OK;
+  if (dmalloc(&c->d_isum, 2 * (uint64_t)c->nregions + 2) || dmalloc(&c->d_ilens, (uint64_t)c->nregions * SHK_REGION) ||
+      dmalloc(&c->d_fin_i, (uint64_t)c->nregions + 2) || dmalloc(&c->d_prot, (uint64_t)SHK_PROT_CAP)) return SHK_ERR_HIP;
+  return SHK_OK;
+}
+
+static void point_scans(shk_ctx *c, bool final_table, bool inter_table, long long carry) {
+  const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
+  const uint32_t img_slots = (uint32_t)SHK_IMG_SLOTS;
+  ProfScope ps(c, KP_REGION_SCAN);
+  if (final_table) {
+    hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b, (uint32_t)SHK_SUM_STRIDE);
+    hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f, 0LL);
+    hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
+                       c->xnslots, img_slots, c->fin[c->cur ^ 1], c->d_counters, c->d_err, (uint32_t)SHK_SUM_STRIDE);
+  }
+  if (inter_table) {
+    // the table in between: free pointers at the region starts (its capacity flags count like the final table's)
+    hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_a, c->d_tile_b, 2u);
+    hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f, carry);
+    hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_f,
+                       c->xnslots, img_slots, c->d_fin_i, c->d_counters, c->d_err, 2u);
+  }
+}
+
+static int point_read(shk_ctx *c, PointOut *po) {
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, (4 + SHK_HIST_BINS + 2) * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  po->newd_after = c->h_pinned[0]; po->added_after = c->h_pinned[1]; po->removed = c->h_pinned[2]; po->added_before = c->h_pinned[3];
+  po->err = *(uint32_t *)(c->h_pinned + 40);
+  if (po->err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  return SHK_OK;
+}
+
+// with_chist: the pass also records the first chunk of every key the table has not seen; c->h_chist[lo..hi] afterwards
+static int point_try(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t split, uint32_t hi, bool with_chist, PointOut *po) {
+  int rc = point_alloc(c);
+  if (rc) return rc;
+  if (with_chist) { rc = ensure_chist(c); if (rc) return rc; }
+  ShkMergeArgs A;
+  fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
+  A.split = split; A.isum = c->d_isum; A.ilens = c->d_ilens;
+  if (with_chist) { A.want_hist = 2; A.newchunks = c->d_newchunks; }
+  { const char *sp = getenv("SHK_STAMPS");
+    A.dbg = (sp && strcmp(sp, "plain") != 0) ? (unsigned long long *)(c->d_scalars + 16) : nullptr; }
+  c->spill_valid = 0;
+  c->chist_n = 0;
+  HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 2) * 8, c->stream));
+  { ProfScope ps(c, KP_MERGE_FUSED);
+    SHK_FOR_REGION_SLICES(c, A, nblk)
+      hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A); }
+  point_scans(c, true, true, 0);
+  if (with_chist) {
+    ProfScope ps(c, KP_MISC);
+    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+    hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
+                       c->d_newchunks, c->d_summary, c->nregions, c->d_chist, 1u);
+    HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 48, c->d_fin_i + c->nregions, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 49, c->d_ilens, 1, hipMemcpyDeviceToHost, c->stream));
+  rc = point_read(c, po);
+  if (rc) return rc;
+  po->islots = c->h_pinned[4 + SHK_HIST_BINS + 1];
+  po->ifin = c->h_pinned[48];
+  po->first_used = (c->h_pinned[49] & 0xff) != 0;
+  if (with_chist && !po->err) c->chist_n = hi + 1;
+  return SHK_OK;
+}
+
+// the range walk of the round over the intermediate layout (k_denoise_marks_virtual). carry: what the shards in front of
+// this one spill over the border (slots, >= 0); W/state: see ShkWalkShard. *nprot singletons, their quotients in c->d_prot.
+static int point_walk(shk_ctx *c, long long carry, const ShkWalkShard &W, const uint64_t state_in[2], uint64_t state_out[2],
+                      uint64_t *nprot, uint32_t *err) {
+  const uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
+  if (carry > 0) point_scans(c, false, true, carry);      // the layout as it is in the single table
+  c->h_pinned[50] = state_in[0]; c->h_pinned[51] = state_in[1];
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 8, c->h_pinned + 50, 16, hipMemcpyHostToDevice, c->stream));
+  { ProfScope ps(c, KP_MARKS);
+    hipLaunchKernelGGL(k_denoise_marks_virtual, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->d_fin_i, (const uint8_t *)c->d_ilens,
+                       (const uint32_t *)c->d_isum, c->nslots, c->xnslots, ml, c->d_prot, SHK_PROT_CAP, (unsigned long long *)(c->d_scalars + 3),
+                       W, (const uint64_t *)(c->d_scalars + 8), c->d_scalars + 10); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 47, c->d_scalars + 3, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 52, c->d_scalars + 10, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *nprot = c->h_pinned[47];
+  state_out[0] = c->h_pinned[52]; state_out[1] = c->h_pinned[53];
+  *err = *(uint32_t *)(c->h_pinned + 40);
+  if (*err) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
+  return SHK_OK;
+}
+
+// the regions that hold a protected singleton, once more with the list; statistics of the whole pass again
+static int point_finish(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t split, uint32_t hi, uint64_t nprot, PointOut *po) {
+  if (nprot > SHK_PROT_CAP) { po->err |= SHK_E_FUSED; return SHK_OK; }
+  if (nprot) {
+    std::vector<uint64_t> prot(nprot);
+    HIPCHK(hipMemcpyAsync(prot.data(), c->d_prot, nprot * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> regs;
+    for (uint64_t q : prot) { const uint32_t r = (uint32_t)(q >> SHK_REGION_LOG2); if (regs.empty() || regs.back() != r) regs.push_back(r); }
+    ShkMergeArgs A;
+    fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
+    A.split = split; A.isum = c->d_isum; A.ilens = c->d_ilens;
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 2) * 8, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_over_list, regs.data(), regs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    A.list = c->d_over_list; A.prot_list = c->d_prot; A.nprot = (uint32_t)nprot;
+    { ProfScope ps(c, KP_MISC);
+      hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3((uint32_t)regs.size()), dim3(c->merge_group), 0, c->stream, A); }
+    HIPCHK(hipStreamSynchronize(c->stream));   // (regs lives on this stack frame)
+    point_scans(c, true, false, 0);
+    int rc = point_read(c, po);
+    if (rc) return rc;
+  }
+  if (!po->err) {
+    c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = 1; c->spill_big = c->big_image;
+    c->spill_nover = 0;
+  }
+  return SHK_OK;
+}
+
 // verify: cstar is a GUESS (sample_locate). The pass then also records the first chunk of every key the table has not seen,
 // like the plain pass does; if the exact histogram puts the point at cstar the pass stands, otherwise nothing is committed
 // and *exact_ch / *crossing (1: the trigger is reached at chunk *exact_ch, 0: not reached in [lo, hi]) say what is true.
@@ -652,115 +791,56 @@ static int denoise_fused(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   *done = false;
   if (crossing) *crossing = -1;
   if (!c->use_spill || c->big_image || c->single_ok || getenv("SHK_NO_FUSED_POINT")) return SHK_OK;
-  if (verify) { int rc = ensure_chist(c); if (rc) return rc; }
-  if (!c->d_isum) {
-    if (dmalloc(&c->d_isum, 2 * (uint64_t)c->nregions + 2) || dmalloc(&c->d_ilens, (uint64_t)c->nregions * SHK_REGION) ||
-        dmalloc(&c->d_fin_i, (uint64_t)c->nregions + 2) || dmalloc(&c->d_prot, (uint64_t)SHK_PROT_CAP)) return SHK_ERR_HIP;
-  }
-  const uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
-  const uint32_t ntiles = (c->nregions + SHK_RSCAN_TILE - 1) / SHK_RSCAN_TILE;
-  const uint32_t img_slots = (uint32_t)SHK_IMG_SLOTS;
-  ShkMergeArgs A;
-  fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
-  A.split = cstar; A.isum = c->d_isum; A.ilens = c->d_ilens;
-  if (verify) { A.want_hist = 2; A.newchunks = c->d_newchunks; }
-  c->spill_valid = 0;
-  c->chist_n = 0;
-  uint64_t nprot = 0;
-  std::vector<uint64_t> prot;
-  for (int go = 0; go < 2; go++) {
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, (4 + SHK_HIST_BINS + 1) * 8, c->stream));
-    { ProfScope ps(c, go == 0 ? KP_MERGE_FUSED : KP_MISC);
-      if (go == 0) {
-        SHK_FOR_REGION_SLICES(c, A, nblk)
-          hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
-        A.r0 = 0;
-      } else {
-        // the regions that hold a protected singleton, once more with the list
-        std::vector<uint32_t> regs;
-        for (uint64_t q : prot) { const uint32_t r = (uint32_t)(q >> SHK_REGION_LOG2); if (regs.empty() || regs.back() != r) regs.push_back(r); }
-        HIPCHK(hipMemcpyAsync(c->d_over_list, regs.data(), regs.size() * 4, hipMemcpyHostToDevice, c->stream));
-        A.list = c->d_over_list; A.prot_list = c->d_prot; A.nprot = (uint32_t)nprot;
-        A.want_hist = 0; A.newchunks = nullptr;
-        hipLaunchKernelGGL((k_region_merge<3, SHK_IMG_BLOCKS, true>), dim3((uint32_t)regs.size()), dim3(c->merge_group), 0, c->stream, A);
-        HIPCHK(hipStreamSynchronize(c->stream));   // (regs lives on this stack frame)
-      } }
-    { ProfScope ps(c, KP_REGION_SCAN);
-      hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_a, c->d_tile_b, (uint32_t)SHK_SUM_STRIDE);
-      hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
-      hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_summary, c->nregions, c->d_tile_f,
-                         c->xnslots, img_slots, c->fin[c->cur ^ 1], c->d_counters, c->d_err, (uint32_t)SHK_SUM_STRIDE);
-      if (go == 0) {
-        // the table in between: free pointers at the region starts (its capacity flags count like the final table's)
-        hipLaunchKernelGGL(k_region_scan_a, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_a, c->d_tile_b, 2u);
-        hipLaunchKernelGGL(k_region_scan_b, dim3(1), dim3(c->threads), 0, c->stream, c->d_tile_a, c->d_tile_b, ntiles, c->d_tile_f);
-        hipLaunchKernelGGL(k_region_scan_c, dim3(ntiles), dim3(c->threads), 0, c->stream, c->d_isum, c->nregions, c->d_tile_f,
-                           c->xnslots, img_slots, c->d_fin_i, c->d_counters, c->d_err, 2u);
-      } }
-    if (go == 0 && verify) {
-      ProfScope ps(c, KP_MISC);
-      HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
-      hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
-                         c->d_newchunks, c->d_summary, c->nregions, c->d_chist, 1u);
-      HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    }
-    if (go == 0) {
-      ProfScope ps(c, KP_MARKS);
-      hipLaunchKernelGGL(k_denoise_marks_virtual, dim3(1), dim3(64), 0, c->stream, (const uint64_t *)c->d_fin_i, (const uint8_t *)c->d_ilens,
-                         (const uint32_t *)c->d_isum, c->nslots, c->xnslots, ml, c->d_prot, SHK_PROT_CAP, (unsigned long long *)(c->d_scalars + 3));
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(c->h_pinned, c->d_counters, 4 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
-    if (go == 0) HIPCHK(hipMemcpyAsync(c->h_pinned + 47, c->d_scalars + 3, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const uint32_t err = *(uint32_t *)(c->h_pinned + 40);
-    if (err) {                                   // not this way: nothing was committed
-      HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
-      if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED fallback: flags 0x%x (go %d)\n", err, go);
-      return SHK_OK;
-    }
-    if (go == 0 && verify) {
-      // where the running distinct count really reaches the trigger (the loop of merge_stage_from)
-      uint64_t run = c->ndistinct;
-      uint32_t ch = lo;
-      for (; ch < hi; ch++) {
-        run += c->h_chist[ch];
-        if (run >= c->cfg.ndistinct_for_denoise) break;
-      }
-      if (ch == hi) run += c->h_chist[ch];
-      const bool crosses = run >= c->cfg.ndistinct_for_denoise;
-      c->chist_n = hi + 1;
-      if (exact_ch) *exact_ch = ch;
-      if (crossing) *crossing = crosses ? 1 : 0;
-      if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED guess %u exact %u crossing %d\n", cstar, ch, (int)crosses);
-      if (!crosses || ch != cstar) return SHK_OK;
-      newd_before = run - c->ndistinct;
-    }
-    if (go == 0) {
-      nprot = c->h_pinned[47];
-      if (nprot > SHK_PROT_CAP) return SHK_OK;
-      if (nprot == 0) break;
-      prot.resize(nprot);
-      HIPCHK(hipMemcpyAsync(prot.data(), c->d_prot, nprot * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-    }
-  }
-  const uint64_t newd_after = c->h_pinned[0], added_after = c->h_pinned[1], removed = c->h_pinned[2], added_before = c->h_pinned[3];
-  // would the trigger be reached again inside the rest? then the rounds have to be taken one by one
-  if (c->rounds_left > 1 && c->ndistinct + newd_before - removed + newd_after >= c->cfg.ndistinct_for_denoise) return SHK_OK;
-  c->spill_valid = 1; c->spill_words = words; c->spill_lo = lo; c->spill_hi = hi; c->spill_denoise = 1; c->spill_big = c->big_image;
-  c->spill_nover = 0;
-  int rc = merge_write(c, words, lo, hi, 1);
+  PointOut po;
+  int rc = point_try(c, words, lo, cstar, hi, verify, &po);
   if (rc) return rc;
-  c->nelts = c->nelts + added_before - removed + added_after;      // inserts, CQF_mt.h:1037-1038, inserts
-  c->ndistinct = c->ndistinct + newd_before - removed + newd_after;
+  if (po.err) {                                  // not this way: nothing was committed
+    if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED fallback: flags 0x%x\n", po.err);
+    return SHK_OK;
+  }
+  if (verify) {
+    // where the running distinct count really reaches the trigger (the loop of merge_stage_from)
+    uint64_t run = c->ndistinct;
+    uint32_t ch = lo;
+    for (; ch < hi; ch++) {
+      run += c->h_chist[ch];
+      if (run >= c->cfg.ndistinct_for_denoise) break;
+    }
+    if (ch == hi) run += c->h_chist[ch];
+    const bool crosses = run >= c->cfg.ndistinct_for_denoise;
+    if (exact_ch) *exact_ch = ch;
+    if (crossing) *crossing = crosses ? 1 : 0;
+    if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED guess %u exact %u crossing %d\n", cstar, ch, (int)crosses);
+    if (!crosses || ch != cstar) return SHK_OK;
+    newd_before = run - c->ndistinct;
+  }
+  ShkWalkShard W;
+  W.prev_fp = -1; W.cap_local = c->nslots; W.last = 1; W.next_first_used = 0;
+  const uint64_t s_in[2] = {0, 0};
+  uint64_t s_out[2], nprot = 0;
+  uint32_t werr = 0;
+  rc = point_walk(c, 0, W, s_in, s_out, &nprot, &werr);
+  if (rc) return rc;
+  if (werr) return SHK_OK;
+  rc = point_finish(c, words, lo, cstar, hi, nprot, &po);
+  if (rc) return rc;
+  if (po.err) {
+    c->spill_valid = 0;
+    if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED fallback: flags 0x%x (second go)\n", po.err);
+    return SHK_OK;
+  }
+  // would the trigger be reached again inside the rest? then the rounds have to be taken one by one
+  if (c->rounds_left > 1 && c->ndistinct + newd_before - po.removed + po.newd_after >= c->cfg.ndistinct_for_denoise) { c->spill_valid = 0; return SHK_OK; }
+  rc = merge_write(c, words, lo, hi, 1);
+  if (rc) return rc;
+  c->nelts = c->nelts + po.added_before - po.removed + po.added_after;      // inserts, CQF_mt.h:1037-1038, inserts
+  c->ndistinct = c->ndistinct + newd_before - po.removed + po.newd_after;
   c->rounds_left--; c->rounds_done++;
-  st->removed += removed; st->denoise_rounds++;
-  st->kmers += added_before + added_after; st->new_distinct += newd_before + newd_after; st->chunks += hi - lo + 1;
+  st->removed += po.removed; st->denoise_rounds++;
+  st->kmers += po.added_before + po.added_after; st->new_distinct += newd_before + po.newd_after; st->chunks += hi - lo + 1;
   *done = true;
   if (getenv("SHK_DEBUG_FUSED")) fprintf(stderr, "SHK_DEBUG_FUSED one-pass point at chunk %u of [%u, %u]: removed %llu protected %llu\n", cstar, lo, hi,
-                                         (unsigned long long)removed, (unsigned long long)nprot);
+                                         (unsigned long long)po.removed, (unsigned long long)nprot);
   return SHK_OK;
 }
 
@@ -779,13 +859,11 @@ static int denoise_round(shk_ctx *c, uint64_t *removed) {
 // first-chunk record, scaled up: regions are hash buckets, so the sample's per-chunk counts of new keys are the whole
 // table's divided by the stride, up to Poisson noise (variance of the scaled sum = stride x sum). The answer is only a
 // guess -- the one-pass point that is run with it checks it against the full histogram it produces itself.
-// verdict 0: no point expected in [lo, hi]; 1: expected at chunk *guess; 2: cannot tell
-static int sample_locate(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int *verdict, uint32_t *guess) {
-  *verdict = 2;
-  if (c->ndistinct >= c->cfg.ndistinct_for_denoise) return SHK_OK;
+// sample_pass: c->h_chist[lo..hi] = the sample's histogram; *ns regions of c->nregions were looked at
+static int sample_pass(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, uint32_t *ns_out, uint32_t *err_out) {
   int rc = ensure_chist(c);
   if (rc) return rc;
-  const uint32_t stride = c->sample_stride;
+  const uint32_t stride = c->sample_stride > 1 ? c->sample_stride : 1;
   const uint32_t ns = (c->nregions + stride - 1) / stride;
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, lo, 0, 0, 2);
@@ -805,11 +883,20 @@ static int sample_locate(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(c->h_pinned + 40, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  const uint32_t err = *(uint32_t *)(c->h_pinned + 40);
-  if (err) {                       // whatever it is, the full pass will meet it again and deal with it
-    HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
-    return SHK_OK;
-  }
+  *err_out = *(uint32_t *)(c->h_pinned + 40);
+  if (*err_out) HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));   // whatever it is, the full pass will meet it again and deal with it
+  *ns_out = ns;
+  return SHK_OK;
+}
+
+// verdict 0: no point expected in [lo, hi]; 1: expected at chunk *guess; 2: cannot tell
+static int sample_locate(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t hi, int *verdict, uint32_t *guess) {
+  *verdict = 2;
+  if (c->ndistinct >= c->cfg.ndistinct_for_denoise) return SHK_OK;
+  uint32_t ns = 0, err = 0;
+  int rc = sample_pass(c, words, lo, hi, &ns, &err);
+  if (rc) return rc;
+  if (err) return SHK_OK;
   const double F = (double)c->nregions / (double)ns;
   const double need = (double)(c->cfg.ndistinct_for_denoise - c->ndistinct);
   double cum = 0;
@@ -1283,6 +1370,70 @@ extern "C" int shk_stage_try_denoise(shk_ctx *c, uint32_t lo, uint32_t hi, shk_s
 extern "C" int shk_stage_chunk_hist(shk_ctx *c, uint64_t *out, uint32_t n) {
   if (!c || !out || !c->chist_n || n > c->chist_n) return SHK_ERR_ARG;
   memcpy(out, c->h_chist, (size_t)n * sizeof(uint64_t));
+  return SHK_OK;
+}
+
+// ---- one-pass deNoise point on a shard (shk/dist.py: the ranks take the steps together)
+extern "C" int shk_stage_sample(shk_ctx *c, uint32_t lo, uint32_t hi, uint64_t *hist, uint32_t *regions, uint32_t *sampled,
+                                uint32_t *err_bits) {
+  if (!c || !hist || !regions || !sampled || !err_bits || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  uint32_t ns = 0, err = 0;
+  int rc = sample_pass(c, c->d_words[c->staged], lo, hi, &ns, &err);
+  prof_collect(c);
+  if (rc) return rc;
+  memcpy(hist, c->h_chist, ((size_t)hi + 1) * sizeof(uint64_t));
+  *regions = c->nregions; *sampled = ns; *err_bits = err;
+  return SHK_OK;
+}
+
+extern "C" int shk_stage_point_try(shk_ctx *c, uint32_t lo, uint32_t split, uint32_t hi, shk_point *out) {
+  if (!c || !out || hi < lo || split < lo || split > hi || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (!c->use_spill || c->single_ok) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  c->pt_valid = 0;
+  memset(out, 0, sizeof(*out));
+  if (c->big_image) { out->err_bits = SHK_E_FUSED; return SHK_OK; }     // (the retry image is not instantiated for this pass)
+  PointOut po;
+  int rc = point_try(c, c->d_words[c->staged], lo, split, hi, true, &po);
+  prof_collect(c);
+  if (rc) return rc;
+  out->new_after = po.newd_after; out->added_after = po.added_after; out->removed = po.removed; out->added_before = po.added_before;
+  out->err_bits = po.err; out->first_used = (uint32_t)po.first_used; out->islots = po.islots; out->ifin = po.ifin;
+  if (!po.err) { c->pt_lo = lo; c->pt_split = split; c->pt_hi = hi; c->pt_valid = 1; c->pt_nprot = 0; }
+  return SHK_OK;
+}
+
+extern "C" int shk_stage_point_walk(shk_ctx *c, int64_t carry, int64_t prev_fp, int last, int next_first_used,
+                                    const uint64_t state_in[2], uint64_t state_out[2], uint64_t *nprot, uint32_t *err_bits) {
+  if (!c || !state_in || !state_out || !nprot || !err_bits || carry < 0 || !c->pt_valid) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  ShkWalkShard W;
+  W.prev_fp = prev_fp; W.cap_local = c->g_nslots - c->q_lo; W.last = last; W.next_first_used = next_first_used;
+  int rc = point_walk(c, carry, W, state_in, state_out, nprot, err_bits);
+  prof_collect(c);
+  if (rc) return rc;
+  c->pt_nprot = *nprot;
+  return SHK_OK;
+}
+
+extern "C" int shk_stage_point_finish(shk_ctx *c, shk_point *out, shk_summary *accept) {
+  if (!c || !out || !accept || !c->pt_valid || !c->chist_n) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  PointOut po;
+  po.newd_after = out->new_after; po.added_after = out->added_after; po.removed = out->removed; po.added_before = out->added_before;
+  po.err = 0;
+  int rc = point_finish(c, c->d_words[c->staged], c->pt_lo, c->pt_split, c->pt_hi, c->pt_nprot, &po);
+  prof_collect(c);
+  c->pt_valid = 0;
+  if (rc) return rc;
+  out->new_after = po.newd_after; out->added_after = po.added_after; out->removed = po.removed; out->added_before = po.added_before;
+  out->err_bits = po.err;
+  uint64_t newd_before = 0;
+  for (uint32_t ch = c->pt_lo; ch <= c->pt_split; ch++) newd_before += c->h_chist[ch];
+  memset(accept, 0, sizeof(*accept));
+  accept->new_distinct = newd_before + po.newd_after; accept->added = po.added_before + po.added_after; accept->removed = po.removed;
+  accept->err_bits = po.err;
   return SHK_OK;
 }
 

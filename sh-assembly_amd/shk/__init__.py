@@ -42,6 +42,12 @@ class Summary(C.Structure):
                 ("hist", C.c_uint64 * 32), ("err_bits", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class Point(C.Structure):
+    """shk_point (include/shk.h): one shard's share of a one-pass deNoise point"""
+    _fields_ = [("new_after", C.c_uint64), ("added_after", C.c_uint64), ("removed", C.c_uint64), ("added_before", C.c_uint64),
+                ("islots", C.c_uint64), ("ifin", C.c_uint64), ("first_used", C.c_uint32), ("err_bits", C.c_uint32)]
+
+
 SOFT_BITS = 0x0A
 HASH_FULL_BIT = 0x04
 LOOKBACK_BIT = 0x100
@@ -59,7 +65,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_stage_sample", "shk_stage_point_try", "shk_stage_point_walk", "shk_stage_point_finish", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -93,6 +99,10 @@ def load(path=None):
     L.shk_stage_accept.argtypes = [vp, C.POINTER(Summary)]
     L.shk_stage_try_denoise.argtypes = [vp, u32, u32, C.POINTER(Summary)]
     L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
+    L.shk_stage_sample.argtypes = [vp, u32, u32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.shk_stage_point_try.argtypes = [vp, u32, u32, u32, C.POINTER(Point)]
+    L.shk_stage_point_walk.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    L.shk_stage_point_finish.argtypes = [vp, C.POINTER(Point), C.POINTER(Summary)]
     L.shk_extend_forward.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32, u64, i32, u32, C.c_char_p, C.POINTER(u32),
                                      C.POINTER(u32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(u32)]
     L.shk_find_unitigs.argtypes = [vp, C.c_char_p, C.POINTER(u32), u32, u32, u64, u32, C.c_char_p, vp]
@@ -301,6 +311,31 @@ class Context:
         self._chk(self.L.shk_find_unitigs(self.h, b"".join(seeds), sc, n, k, abundance_min, max_len, out_path.encode(),
                                           C.cast(st, C.c_void_p)))
         return dict(zip(("unitigs", "total_len", "rounds", "extensions", "duplicates", "truncated"), list(st)))
+
+    def stage_sample(self, lo, hi):
+        """(hist[0..hi] of the sampled regions, regions, sampled regions, kernel flag bits)"""
+        out = (C.c_uint64 * (hi + 1))()
+        nr, ns, eb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.shk_stage_sample(self.h, lo, hi, out, C.byref(nr), C.byref(ns), C.byref(eb)))
+        return list(out), nr.value, ns.value, eb.value
+
+    def stage_point_try(self, lo, split, hi):
+        p = Point()
+        self._chk(self.L.shk_stage_point_try(self.h, lo, split, hi, C.byref(p)))
+        return p
+
+    def stage_point_walk(self, carry, prev_fp, last, next_first_used, state):
+        """-> (state for the next shard, protected singletons on this shard, kernel flag bits)"""
+        sin = (C.c_uint64 * 2)(*state)
+        sout = (C.c_uint64 * 2)()
+        n, eb = C.c_uint64(), C.c_uint32()
+        self._chk(self.L.shk_stage_point_walk(self.h, carry, prev_fp, int(last), int(next_first_used), sin, sout, C.byref(n), C.byref(eb)))
+        return (sout[0], sout[1]), n.value, eb.value
+
+    def stage_point_finish(self, point):
+        acc = Summary()
+        self._chk(self.L.shk_stage_point_finish(self.h, C.byref(point), C.byref(acc)))
+        return acc
 
     def stage_try_denoise(self, lo, hi):
         s = Summary()

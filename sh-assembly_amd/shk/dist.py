@@ -18,7 +18,7 @@ import torch.distributed as dist
 
 from . import HASH_FULL_BIT, HIST_BINS, LOOKBACK_BIT, SOFT_BITS, ShkError, Summary
 
-NBITS = 9        # kernel flag bits (csrc/shk_device.h SHK_E_*)
+NBITS = 10       # kernel flag bits (csrc/shk_device.h SHK_E_*)
 NCODES = 8       # SHK_ERR_* codes -1 .. -8 (include/shk.h)
 
 
@@ -32,6 +32,10 @@ class ShardState:
         self.device = device
         self.pending_rc = 0         # return code of a rank-local call not yet shown to the peers
         self.collectives = 0        # small all-reduces issued (diagnostics)
+        self.one_pass_points = 0    # deNoise points taken in one rebuild per shard (_one_pass_point)
+        self.other_points = 0       # ... and on the three-pass path
+        self.guesses = 0            # sampled predictions of the point's chunk, and how many the exact histogram confirmed
+        self.guesses_right = 0
 
 
 def _allreduce(vals, st, op=None):
@@ -125,9 +129,138 @@ def _point(st, d, lo, hi):
     return hi
 
 
+def _codes(st):
+    return [1 if st.pending_rc == -c else 0 for c in range(1, NCODES + 1)]
+
+
+def _raise_codes(ctx, st, codes):
+    for c in range(1, NCODES + 1):
+        if codes[c - 1]:
+            st.pending_rc = 0
+            raise ShkError(-c, "%s (on %d of the ranks)" % (ctx.L.shk_strerror(-c).decode(), codes[c - 1]))
+
+
+def _sample_stride(ctx):
+    """the library's rule (csrc/shk_api.hip shk_create): every 8th region once a shard has 2^14 of them"""
+    e = os.environ.get("SHK_SAMPLE_STRIDE")
+    if e is not None:
+        return int(e)
+    return 8 if ctx.totals().nslots >= (1 << 22) else 0
+
+
+def _sample_point(ctx, st, lo, hi):
+    """-> (verdict, chunk): 0 no deNoise point expected in [lo, hi], 1 expected at `chunk`, 2 cannot tell. One statistics
+    pass over a sample of every shard's regions, one all-reduce (the library's sample_locate, filter-wide)."""
+    n = hi - lo + 1
+    h, nr, ns, eb = _local(st, lambda: ctx.stage_sample(lo, hi), ([0] * (hi + 1), 0, 0, 1))
+    red = _allreduce(list(h[lo:hi + 1]) + [nr, ns, 1 if eb else 0] + _codes(st), st)
+    _raise_codes(ctx, st, red[n + 3:])
+    if red[n + 2] or not red[n + 1] or st.ndistinct >= st.trigger:
+        return 2, 0
+    scale = red[n] / red[n + 1]
+    need = st.trigger - st.ndistinct
+    cum, at = 0.0, None
+    for i in range(n):
+        cum += scale * red[i]
+        if at is None and cum >= need:
+            at = lo + i
+    margin = 6.0 * (scale * cum + 1.0) ** 0.5
+    if cum + margin < need:
+        return 0, 0
+    if cum - margin >= need and at is not None:
+        return 1, at
+    return 2, 0
+
+
+def _dbg(msg):
+    if os.environ.get("SHK_DEBUG_FUSED") and dist.get_rank() == 0:
+        print("SHK_DEBUG_FUSED (sharded)", msg, flush=True)
+
+
+def _one_pass_point(ctx, st, lo, split, hi, out):
+    """The deNoise point after global chunk `split`, the round and the chunks behind it in ONE rebuild per shard
+    (include/shk.h shk_stage_point_*). `split` may be a guess: the pass records the exact first-chunk histogram and the
+    ranks check it. Returns "done", or the exact chunk of the point when `split` was wrong, or None (not this way:
+    nothing has been written; the caller takes the three-pass path)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = hi - lo + 1
+    p = _local(st, lambda: ctx.stage_point_try(lo, split, hi), None)
+    ok = p is not None and not p.err_bits
+    h = (_local(st, lambda: ctx.stage_chunk_hist(hi + 1), None) if ok and not st.pending_rc else None)
+    bits = 0xFFFF if p is None else p.err_bits
+    mine = [0, 0, 0] if p is None else [p.islots, p.ifin, p.first_used]
+    slots = [0] * (3 * world)
+    slots[3 * rank:3 * rank + 3] = mine
+    vec = [(bits >> b) & 1 for b in range(NBITS)] + _codes(st) + [0 if h is None else 1] + ([0] * n if h is None else list(h[lo:hi + 1])) + slots
+    red = _allreduce(vec, st)
+    _raise_codes(ctx, st, red[NBITS:NBITS + NCODES])
+    base = NBITS + NCODES
+    if any(red[:NBITS]) or red[base] != world:
+        _dbg("point at %d of [%d, %d]: flags %s" % (split, lo, hi, red[:NBITS]))
+        return None
+    chist = red[base + 1:base + 1 + n]
+    run, ch = st.ndistinct, None
+    for i, v in enumerate(chist):
+        run += v
+        if run >= st.trigger:
+            ch = lo + i
+            break
+    if ch is None:
+        _dbg("guess %d of [%d, %d]: no point in the range" % (split, lo, hi))
+        return None                       # (the trigger is not reached in [lo, hi] at all)
+    if ch != split:
+        _dbg("guess %d of [%d, %d]: the point is at %d" % (split, lo, hi, ch))
+        return ch
+    newd_before = run - st.ndistinct
+    # every shard's table at the split as it lies in the single table: what the shards in front of it carry over its border
+    g = red[base + 1 + n:]
+    size = ctx.totals().nslots           # own quotients per shard (the same on every rank)
+    carry, prev_fp = [0] * world, [-1] * world
+    for r in range(1, world):
+        fend = (r - 1) * size + max(carry[r - 1] + g[3 * (r - 1)], g[3 * (r - 1) + 1])
+        prev_fp[r] = fend - r * size
+        carry[r] = max(0, prev_fp[r])
+    # the round's range walk runs through the shards one after the other (each range starts where the last one ended)
+    state = torch.zeros(2, dtype=torch.int64, device=st.device)
+    if rank > 0:
+        dist.recv(state, src=rank - 1)
+    nxt_used = g[3 * (rank + 1) + 2] if rank + 1 < world else 0
+    so, nprot, web = _local(st, lambda: ctx.stage_point_walk(carry[rank], prev_fp[rank], rank == world - 1, nxt_used,
+                                                             [int(x) for x in state.tolist()]), ((0, 0), 0, 0xFFFF))
+    if rank + 1 < world:
+        dist.send(torch.tensor(list(so), dtype=torch.int64, device=st.device), dst=rank + 1)
+    acc = None
+    if not web and not st.pending_rc:
+        acc = _local(st, lambda: ctx.stage_point_finish(p), None)
+    bad = 1 if (acc is None or acc.err_bits or web) else 0
+    vec = ([0, 0, 0, 0] if bad else [p.new_after, p.added_after, p.removed, p.added_before]) + [bad] + _codes(st)
+    red = _allreduce(vec, st)
+    _raise_codes(ctx, st, red[5:])
+    if red[4]:
+        _dbg("point at %d of [%d, %d]: walk / second go flagged on %d rank(s)" % (split, lo, hi, red[4]))
+        return None
+    new_after, added_after, removed, added_before = red[0:4]
+    if st.rounds_left > 1 and st.ndistinct + newd_before - removed + new_after >= st.trigger:
+        _dbg("point at %d of [%d, %d]: a second point inside the rest" % (split, lo, hi))
+        return None                       # a second point inside the rest: the rounds are taken one by one
+    _local(st, lambda: ctx.stage_accept(acc))
+    st.ndistinct += newd_before - removed + new_after
+    st.nelts += added_before - removed + added_after
+    st.rounds_left -= 1
+    st.rounds_done += 1
+    st.one_pass_points += 1
+    out["removed"] += removed
+    out["kmers"] += added_before + added_after
+    out["new_distinct"] += newd_before + new_after
+    out["denoise_rounds"] += 1
+    _dbg("one-pass point at %d of [%d, %d]: removed %d" % (split, lo, hi, removed))
+    return "done"
+
+
 def sharded_count(ctx, st, nchunks):
     """insert the staged words of global chunks [0, nchunks); returns dict(kmers, new_distinct, removed, rounds)"""
     out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
+    stride = _sample_stride(ctx)
 
     def book(d):
         st.ndistinct += d.newd
@@ -144,10 +277,27 @@ def sharded_count(ctx, st, nchunks):
     while lo < nchunks:
         hi = nchunks - 1
         watch = st.rounds_left > 0
+        verdict = 2
+        if watch and stride > 1 and not os.environ.get("SHK_NO_FUSED_POINT"):
+            # where the deNoise point falls, guessed from a sample of the regions; the one-pass point checks the guess
+            verdict, guess = _sample_point(ctx, st, lo, hi)
+            _dbg("sample of [%d, %d]: verdict %d at %d" % (lo, hi, verdict, guess))
+            if verdict == 1 and guess + 1 < nchunks:
+                st.guesses += 1
+                r = _one_pass_point(ctx, st, lo, guess, nchunks - 1, out)
+                if r == "done":
+                    st.guesses_right += 1
+                    lo = nchunks
+                    continue
+                if r is not None and r + 1 < nchunks:
+                    if _one_pass_point(ctx, st, lo, r, nchunks - 1, out) == "done":
+                        lo = nchunks
+                        continue
         # common case: one try per rank does statistics (and, in the single-launch scheme, the table); accepted when
         # no rank saw an error and the whole filter stays below the trigger. While rounds are left the try also
         # records first chunks and their histogram rides along, so a deNoise point is located without more passes.
-        d = _decide(ctx, st, lambda: ctx.stage_try(lo, hi, lo, 0, 2 if watch else 0), (lo, hi) if watch else None)
+        wh = watch and verdict != 0      # (verdict 0: the sample rules a point out; should it be wrong the summary below is redone)
+        d = _decide(ctx, st, lambda: ctx.stage_try(lo, hi, lo, 0, 2 if wh else 0), (lo, hi) if wh else None)
         if d.hard:
             fail(d)
         crosses = watch and st.ndistinct + d.newd >= st.trigger
@@ -176,6 +326,11 @@ def sharded_count(ctx, st, nchunks):
             crosses = watch and st.ndistinct + d.newd >= st.trigger
             if crosses and d.chist is not None:
                 point = _point(st, d, lo, hi)
+        if crosses and point is not None and point + 1 < nchunks and hi == nchunks - 1 and not os.environ.get("SHK_NO_FUSED_POINT"):
+            # the exact chunk is known and the point lies inside the batch: everything in one rebuild per shard
+            if _one_pass_point(ctx, st, lo, point, nchunks - 1, out) == "done":
+                lo = nchunks
+                continue
         fire = False
         accepted = False
         if crosses:
@@ -224,6 +379,7 @@ def sharded_count(ctx, st, nchunks):
         if fire:
             st.rounds_left -= 1
             st.rounds_done += 1
+            st.other_points += 1
             out["denoise_rounds"] += 1
             fused = False
             if hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
@@ -286,6 +442,26 @@ def wrap_bytes(ptr, n, device):
     return torch.frombuffer((ctypes.c_uint8 * n).from_address(ptr), dtype=torch.uint8)
 
 
+def _recv_buffer(ctx, n, device):
+    """Receive side of the all-to-all: two buffers per context, used alternately (batch s is staged from one while batch
+    s + 1 arrives in the other), each as large as a batch may be (max_batch_keys: more could not be staged anyway). A fresh
+    multi-GB tensor per batch would go through the caching allocator with a different size every time -- on an MI355X
+    that more than doubled the time of a step (bench.py --force-dist: 123 ms against 54)."""
+    if device.type != "cuda":
+        return torch.empty((n,), dtype=torch.int64, device=device)
+    cap = int(ctx.cfg.max_batch_keys)
+    if n > cap:
+        raise ShkError(-7, "more key words for this shard (%d) than max_batch_keys (%d)" % (n, cap))
+    pool = getattr(ctx, "_recv_pool", None)
+    if pool is None:
+        pool = ctx._recv_pool = {"bufs": [None, None], "next": 0}
+    i = pool["next"]
+    pool["next"] ^= 1
+    if pool["bufs"][i] is None:
+        pool["bufs"][i] = torch.empty((cap,), dtype=torch.int64, device=device)
+    return pool["bufs"][i][:n]
+
+
 class Exchange:
     """one all-to-all of key words in flight: start() after shk_route_words, wait() before shk_stage_words. Between the
     two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
@@ -302,13 +478,15 @@ class Exchange:
         allc = allc.view(world, world).tolist()
         rc = [allc[p][rank] for p in range(world)]
         mx = max(max(row) for row in allc)
-        self.recv = torch.empty((sum(rc),), dtype=torch.int64, device=device)
+        self.recv = _recv_buffer(ctx, sum(rc), device)
         soff = [sum(sc[:p]) for p in range(world)]
         roff = [sum(rc[:p]) for p in range(world)]
         self.work = []
-        if world == 1 and not os.environ.get("SHK_A2A_NO_BYPASS"):     # (the variable lets a one-rank test drive the collective)
+        if world == 1 and device.type != "cuda":
             self.recv.copy_(self.send)
             return
+        # (one rank on a GPU still goes through RCCL: its self-send copies with a few workgroups next to the running
+        # kernels -- a plain tensor copy on torch's stream takes the whole chip and cost 16 ms per 832 M-key step)
         piece_words = int(os.environ.get("SHK_ROUTE_PIECE", ROUTE_PIECE))
         grouped = device.type == "cuda" and not os.environ.get("SHK_A2A_SINGLE")
         for r0 in range(0, max(mx, 1), piece_words):

@@ -16,15 +16,16 @@ from fastq_util import chunks_by_records
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "libshk_emu.so")
 QB, K, TRIG, ND, ML = 11, 28, 650, 2, 1 << 20
+TRIG_ONE_PASS = {2: 420, 4: 880}   # (chosen so that no batch holds two points: every point goes the one-pass way)
 
 
-def _data(rank):
+def _data(rank, shape=(24, 6)):
     g = synth.make_genome(300, 7)
-    fq = synth.make_fastq(g, 24, 90, 0.01, seed=50 + rank, n_frac=0.05)
-    return fq, chunks_by_records(fq, 6)
+    fq = synth.make_fastq(g, shape[0], 90, 0.01, seed=50 + rank, n_frac=0.05)
+    return fq, chunks_by_records(fq, shape[1])
 
 
-def _worker(rank, world, port, q, nd=ND, out_path=None):
+def _worker(rank, world, port, q, nd=ND, out_path=None, ml=ML, trig=TRIG, shape=(24, 6)):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "sh-assembly_amd"))
@@ -33,10 +34,10 @@ def _worker(rank, world, port, q, nd=ND, out_path=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
-    fq, (offs, lens) = _data(rank)
-    ctx = shk.Context(qb=QB, k=K, min_denoise_len=ML, max_batch_bytes=1 << 20, max_batch_keys=1 << 16,
+    fq, (offs, lens) = _data(rank, shape)
+    ctx = shk.Context(qb=QB, k=K, min_denoise_len=ml, max_batch_bytes=1 << 20, max_batch_keys=1 << 16,
                       shard_index=rank, num_shards=world, threads_per_group=64, hash_groups=2, lib_path=EMU)
-    st = shkdist.ShardState(TRIG, nd, dev)
+    st = shkdist.ShardState(trig, nd, dev)
     hb = QB + 8
     # two batches, the second one's exchange started before the first is staged (the pipelined form bench.py uses)
     half = len(offs) // 2
@@ -61,18 +62,19 @@ def _worker(rank, world, port, q, nd=ND, out_path=None):
     keys = sorted(set(int(x) & ((1 << hb) - 1) for x in recv.tolist()))
     cnt, _ = ctx.lookup(keys, mode=2)
     t = ctx.totals()
-    q.put((rank, out, st.ndistinct, st.nelts, {k: c for k, c in zip(keys, cnt) if c}, t.ndistinct))
+    q.put((rank, out, st.ndistinct, st.nelts, {k: c for k, c in zip(keys, cnt) if c}, t.ndistinct,
+           (st.one_pass_points, st.other_points, st.guesses, st.guesses_right)))
     ctx.close()
     dist.destroy_process_group()
 
 
-def _run(world, nd, out_path):
+def _run(world, nd, out_path, ml=ML, trig=TRIG, shape=(24, 6)):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
     import torch.multiprocessing as mp
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = 29600 + (os.getpid() * 7 + world * 3 + nd) % 300
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, nd, out_path)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, nd, out_path, ml, trig, shape)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
@@ -83,16 +85,16 @@ def _run(world, nd, out_path):
     # oracle: one filter, chunks in the interleaved order rank0.c0, rank1.c0, rank0.c1, ...
     O = cqflibs.oracle()
     o = O.new(QB)
-    d = [_data(r) for r in range(world)]
+    d = [_data(r, shape) for r in range(world)]
     nch = len(d[0][1][0])
     left, rounds, removed = nd, 0, 0
     for j in range(nch):
         for r in range(world):
             fq, (offs, lens) = d[r]
             o.reads_to_kmers(fq[offs[j]:offs[j] + lens[j]], K)
-            if left and o.ndistinct() >= TRIG:
+            if left and o.ndistinct() >= trig:
                 left -= 1
-                removed += o.denoise_round(ML)
+                removed += o.denoise_round(ml)
                 rounds += 1
     assert not o.full()
     return res, o, rounds
@@ -106,7 +108,7 @@ def test_shards_match_single_filter(world, tmp_path):
     assert all(r[1] == out0 for r in res)               # every rank took the same decisions
     assert out0["denoise_rounds"] == rounds and rounds >= 1
     merged = {}
-    for _, _, _, _, kc, _ in res:
+    for _, _, _, _, kc, _, _ in res:
         assert not (set(kc) & set(merged))
         merged.update(kc)
     truth = dict(o.dump())
@@ -135,6 +137,26 @@ def test_stitched_export_equals_single_table_bytes(tmp_path):
     out_path = str(tmp_path / "stitched.cqf")
     res, o, rounds = _run(2, 0, out_path)
     assert rounds == 0
+    single = str(tmp_path / "single.cqf")
+    o.serialize(single)
+    assert open(out_path, "rb").read() == open(single, "rb").read()
+    o.free()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_pass_points_make_the_shards_the_single_table(world, tmp_path, monkeypatch):
+    """deNoise points taken in one rebuild per shard (shk/dist.py _one_pass_point): the point's chunk guessed from a sample of
+    the regions and verified, the round's range walk (short ranges here: many range ends, some next to a shard border)
+    continued from shard to shard over the layout of the single table. Then NOTHING differs from the single filter: rounds,
+    removed counts, counters, and the stitched file is the oracle's .cqf byte for byte"""
+    monkeypatch.setenv("SHK_SAMPLE_STRIDE", "2")
+    out_path = str(tmp_path / "stitched.cqf")
+    res, o, rounds = _run(world, 2, out_path, ml=64, trig=TRIG_ONE_PASS[world], shape=(24, 2))
+    out0 = res[0][1]
+    assert all(r[1] == out0 for r in res)
+    one_pass, other, guesses, right = res[0][6]
+    assert (one_pass, other) == (2, 0) and rounds == out0["denoise_rounds"] == 2
+    assert (res[0][2], res[0][3]) == (o.ndistinct(), o.nelts())
     single = str(tmp_path / "single.cqf")
     o.serialize(single)
     assert open(out_path, "rb").read() == open(single, "rb").read()

@@ -249,7 +249,6 @@ def test_sharded_flow_one_rank_matches_oracle(monkeypatch):
     import torch.distributed as dist
     from shk import dist as shkdist
     qb, k, trigger, nd, ml = 16, 31, 12000, 3, 1 << 11
-    monkeypatch.setenv("SHK_A2A_NO_BYPASS", "1")      # the exchange goes through RCCL's all_to_all even with one rank
     g = synth.make_genome(12000, 5)
     fq = synth.make_fastq(g, 2400, 100, 0.01, seed=33, n_frac=0.03, short_frac=0.02)
     offs, lens = chunks_by_records(fq, 100)

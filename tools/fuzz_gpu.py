@@ -18,7 +18,6 @@ def main():
         import torch.distributed as dist
         from shk import dist as shkdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        os.environ["SHK_A2A_NO_BYPASS"] = "1"
         dist.init_process_group("nccl", rank=0, world_size=1)
         dev = torch.device("cuda:0")
     rnd = random.Random(args.seed)
