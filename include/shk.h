@@ -209,6 +209,10 @@ typedef struct shk_point {
 int shk_stage_sample(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint64_t *hist, uint32_t *regions, uint32_t *sampled,
                      uint32_t *err_bits);
 int shk_stage_point_try(shk_ctx *ctx, uint32_t chunk_lo, uint32_t split, uint32_t chunk_hi, shk_point *out);
+/* the same for a round on its own (no words: the reference's --endDeNoise round, or a round the batch ends on);
+ * followed by shk_stage_point_walk / _finish / shk_stage_accept like a point. split = chunk_lo - 1 in
+ * shk_stage_point_try puts the round in front of all the staged chunks [chunk_lo, chunk_hi]. */
+int shk_stage_round_try(shk_ctx *ctx, shk_point *out);
 int shk_stage_point_walk(shk_ctx *ctx, int64_t carry, int64_t prev_fp, int last, int next_first_used, const uint64_t state_in[2],
                          uint64_t state_out[2], uint64_t *nprot, uint32_t *err_bits);
 int shk_stage_point_finish(shk_ctx *ctx, shk_point *out, shk_summary *accept);

@@ -88,6 +88,7 @@ struct shk_ctx {
   uint32_t chist_n;             // entries of h_chist valid from the last summary (0 = none)
   uint32_t sample_stride;       // sampled statistics pass before a deNoise point: every n-th region (<= 1: off)
   uint32_t pt_lo, pt_split, pt_hi; int pt_valid; uint64_t pt_nprot;   // one-pass deNoise point in progress (shk_stage_point_*)
+  const uint64_t *pt_words;     // its words (null: a round on its own, shk_stage_round_try)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
   uint32_t *d_err;
   uint64_t *h_pinned;           // pinned mirror: counters(4) hist(32) err(1) scalars(4)
@@ -1388,7 +1389,7 @@ extern "C" int shk_stage_sample(shk_ctx *c, uint32_t lo, uint32_t hi, uint64_t *
 }
 
 extern "C" int shk_stage_point_try(shk_ctx *c, uint32_t lo, uint32_t split, uint32_t hi, shk_point *out) {
-  if (!c || !out || hi < lo || split < lo || split > hi || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (!c || !out || hi < lo || split + 1 < lo || split > hi || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;   // (split = lo - 1: the round comes first)
   if (!c->use_spill || c->single_ok) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   c->pt_valid = 0;
@@ -1400,7 +1401,25 @@ extern "C" int shk_stage_point_try(shk_ctx *c, uint32_t lo, uint32_t split, uint
   if (rc) return rc;
   out->new_after = po.newd_after; out->added_after = po.added_after; out->removed = po.removed; out->added_before = po.added_before;
   out->err_bits = po.err; out->first_used = (uint32_t)po.first_used; out->islots = po.islots; out->ifin = po.ifin;
-  if (!po.err) { c->pt_lo = lo; c->pt_split = split; c->pt_hi = hi; c->pt_valid = 1; c->pt_nprot = 0; }
+  if (!po.err) { c->pt_lo = lo; c->pt_split = split; c->pt_hi = hi; c->pt_valid = 1; c->pt_nprot = 0; c->pt_words = c->d_words[c->staged]; }
+  return SHK_OK;
+}
+
+// a deNoise round on its own (no words), taken the same way: the range walk then runs over the single table's layout
+extern "C" int shk_stage_round_try(shk_ctx *c, shk_point *out) {
+  if (!c || !out) return SHK_ERR_ARG;
+  if (!c->use_spill || c->single_ok) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  c->pt_valid = 0;
+  memset(out, 0, sizeof(*out));
+  if (c->big_image) { out->err_bits = SHK_E_FUSED; return SHK_OK; }
+  PointOut po;
+  int rc = point_try(c, nullptr, 0, 0, 0, false, &po);
+  prof_collect(c);
+  if (rc) return rc;
+  out->new_after = po.newd_after; out->added_after = po.added_after; out->removed = po.removed; out->added_before = po.added_before;
+  out->err_bits = po.err; out->first_used = (uint32_t)po.first_used; out->islots = po.islots; out->ifin = po.ifin;
+  if (!po.err) { c->pt_lo = 1; c->pt_split = 0; c->pt_hi = 0; c->pt_valid = 1; c->pt_nprot = 0; c->pt_words = nullptr; }
   return SHK_OK;
 }
 
@@ -1418,19 +1437,20 @@ extern "C" int shk_stage_point_walk(shk_ctx *c, int64_t carry, int64_t prev_fp, 
 }
 
 extern "C" int shk_stage_point_finish(shk_ctx *c, shk_point *out, shk_summary *accept) {
-  if (!c || !out || !accept || !c->pt_valid || !c->chist_n) return SHK_ERR_ARG;
+  if (!c || !out || !accept || !c->pt_valid || (c->pt_words && !c->chist_n)) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   PointOut po;
   po.newd_after = out->new_after; po.added_after = out->added_after; po.removed = out->removed; po.added_before = out->added_before;
   po.err = 0;
-  int rc = point_finish(c, c->d_words[c->staged], c->pt_lo, c->pt_split, c->pt_hi, c->pt_nprot, &po);
+  const bool round_only = c->pt_words == nullptr;
+  int rc = point_finish(c, c->pt_words, round_only ? 0 : c->pt_lo, c->pt_split, c->pt_hi, c->pt_nprot, &po);
   prof_collect(c);
   c->pt_valid = 0;
   if (rc) return rc;
   out->new_after = po.newd_after; out->added_after = po.added_after; out->removed = po.removed; out->added_before = po.added_before;
   out->err_bits = po.err;
   uint64_t newd_before = 0;
-  for (uint32_t ch = c->pt_lo; ch <= c->pt_split; ch++) newd_before += c->h_chist[ch];
+  if (!round_only) for (uint32_t ch = c->pt_lo; ch <= c->pt_split; ch++) newd_before += c->h_chist[ch];
   memset(accept, 0, sizeof(*accept));
   accept->new_distinct = newd_before + po.newd_after; accept->added = po.added_before + po.added_after; accept->removed = po.removed;
   accept->err_bits = po.err;

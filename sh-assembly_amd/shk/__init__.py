@@ -65,7 +65,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_stage_sample", "shk_stage_point_try", "shk_stage_point_walk", "shk_stage_point_finish", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_stage_sample", "shk_stage_point_try", "shk_stage_round_try", "shk_stage_point_walk", "shk_stage_point_finish", "shk_upload_text", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -101,6 +101,7 @@ def load(path=None):
     L.shk_stage_chunk_hist.argtypes = [vp, C.POINTER(u64), u32]
     L.shk_stage_sample.argtypes = [vp, u32, u32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.shk_stage_point_try.argtypes = [vp, u32, u32, u32, C.POINTER(Point)]
+    L.shk_stage_round_try.argtypes = [vp, C.POINTER(Point)]
     L.shk_stage_point_walk.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
     L.shk_stage_point_finish.argtypes = [vp, C.POINTER(Point), C.POINTER(Summary)]
     L.shk_extend_forward.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32, u64, i32, u32, C.c_char_p, C.POINTER(u32),
@@ -322,6 +323,11 @@ class Context:
     def stage_point_try(self, lo, split, hi):
         p = Point()
         self._chk(self.L.shk_stage_point_try(self.h, lo, split, hi, C.byref(p)))
+        return p
+
+    def stage_round_try(self):
+        p = Point()
+        self._chk(self.L.shk_stage_round_try(self.h, C.byref(p)))
         return p
 
     def stage_point_walk(self, carry, prev_fp, last, next_first_used, state):

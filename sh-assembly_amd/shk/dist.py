@@ -36,6 +36,7 @@ class ShardState:
         self.other_points = 0       # ... and on the three-pass path
         self.guesses = 0            # sampled predictions of the point's chunk, and how many the exact histogram confirmed
         self.guesses_right = 0
+        self.inexact_rounds = 0     # rounds whose range walk restarted at every shard (only after a flagged one-pass try)
 
 
 def _allreduce(vals, st, op=None):
@@ -177,21 +178,25 @@ def _dbg(msg):
         print("SHK_DEBUG_FUSED (sharded)", msg, flush=True)
 
 
-def _one_pass_point(ctx, st, lo, split, hi, out):
+def _one_pass_point(ctx, st, lo, split, hi, out, known=False, words=True):
     """The deNoise point after global chunk `split`, the round and the chunks behind it in ONE rebuild per shard
     (include/shk.h shk_stage_point_*). `split` may be a guess: the pass records the exact first-chunk histogram and the
     ranks check it. Returns "done", or the exact chunk of the point when `split` was wrong, or None (not this way:
-    nothing has been written; the caller takes the three-pass path)."""
+    nothing has been written; the caller takes another path).
+    known: the round is due whatever the histogram says and has been booked by the caller (split = lo - 1: the round, then
+    the chunks [lo, hi]); words=False: the round alone (shk_stage_round_try)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = hi - lo + 1
-    p = _local(st, lambda: ctx.stage_point_try(lo, split, hi), None)
+    n = hi - lo + 1 if words else 0
+    p = _local(st, (lambda: ctx.stage_point_try(lo, split, hi)) if words else ctx.stage_round_try, None)
     ok = p is not None and not p.err_bits
-    h = (_local(st, lambda: ctx.stage_chunk_hist(hi + 1), None) if ok and not st.pending_rc else None)
+    h = (_local(st, lambda: ctx.stage_chunk_hist(hi + 1), None) if ok and words and not st.pending_rc else None)
+    if ok and not words:
+        h = []
     bits = 0xFFFF if p is None else p.err_bits
     mine = [0, 0, 0] if p is None else [p.islots, p.ifin, p.first_used]
     slots = [0] * (3 * world)
     slots[3 * rank:3 * rank + 3] = mine
-    vec = [(bits >> b) & 1 for b in range(NBITS)] + _codes(st) + [0 if h is None else 1] + ([0] * n if h is None else list(h[lo:hi + 1])) + slots
+    vec = [(bits >> b) & 1 for b in range(NBITS)] + _codes(st) + [0 if h is None else 1] + ([0] * n if h is None else list(h[lo:hi + 1] if words else [])) + slots
     red = _allreduce(vec, st)
     _raise_codes(ctx, st, red[NBITS:NBITS + NCODES])
     base = NBITS + NCODES
@@ -199,19 +204,22 @@ def _one_pass_point(ctx, st, lo, split, hi, out):
         _dbg("point at %d of [%d, %d]: flags %s" % (split, lo, hi, red[:NBITS]))
         return None
     chist = red[base + 1:base + 1 + n]
-    run, ch = st.ndistinct, None
-    for i, v in enumerate(chist):
-        run += v
-        if run >= st.trigger:
-            ch = lo + i
-            break
-    if ch is None:
-        _dbg("guess %d of [%d, %d]: no point in the range" % (split, lo, hi))
-        return None                       # (the trigger is not reached in [lo, hi] at all)
-    if ch != split:
-        _dbg("guess %d of [%d, %d]: the point is at %d" % (split, lo, hi, ch))
-        return ch
-    newd_before = run - st.ndistinct
+    if known:
+        newd_before = sum(chist[:max(0, split - lo + 1)])
+    else:
+        run, ch = st.ndistinct, None
+        for i, v in enumerate(chist):
+            run += v
+            if run >= st.trigger:
+                ch = lo + i
+                break
+        if ch is None:
+            _dbg("guess %d of [%d, %d]: no point in the range" % (split, lo, hi))
+            return None                       # (the trigger is not reached in [lo, hi] at all)
+        if ch != split:
+            _dbg("guess %d of [%d, %d]: the point is at %d" % (split, lo, hi, ch))
+            return ch
+        newd_before = run - st.ndistinct
     # every shard's table at the split as it lies in the single table: what the shards in front of it carry over its border
     g = red[base + 1 + n:]
     size = ctx.totals().nslots           # own quotients per shard (the same on every rank)
@@ -240,21 +248,37 @@ def _one_pass_point(ctx, st, lo, split, hi, out):
         _dbg("point at %d of [%d, %d]: walk / second go flagged on %d rank(s)" % (split, lo, hi, red[4]))
         return None
     new_after, added_after, removed, added_before = red[0:4]
-    if st.rounds_left > 1 and st.ndistinct + newd_before - removed + new_after >= st.trigger:
+    if st.rounds_left > (0 if known else 1) and st.ndistinct + newd_before - removed + new_after >= st.trigger:
         _dbg("point at %d of [%d, %d]: a second point inside the rest" % (split, lo, hi))
         return None                       # a second point inside the rest: the rounds are taken one by one
     _local(st, lambda: ctx.stage_accept(acc))
     st.ndistinct += newd_before - removed + new_after
     st.nelts += added_before - removed + added_after
-    st.rounds_left -= 1
-    st.rounds_done += 1
-    st.one_pass_points += 1
+    if not known:
+        st.rounds_left -= 1
+        st.rounds_done += 1
+        st.one_pass_points += 1
+        out["denoise_rounds"] += 1
     out["removed"] += removed
     out["kmers"] += added_before + added_after
     out["new_distinct"] += newd_before + new_after
-    out["denoise_rounds"] += 1
     _dbg("one-pass point at %d of [%d, %d]: removed %d" % (split, lo, hi, removed))
     return "done"
+
+
+def sharded_denoise(ctx, st):
+    """one deNoise round now on the whole sharded filter (the reference's --endDeNoise round; does not use up the
+    rounds); returns the number of singletons removed"""
+    out = {"kmers": 0, "new_distinct": 0, "removed": 0, "denoise_rounds": 0}
+    if not os.environ.get("SHK_NO_FUSED_POINT") and _one_pass_point(ctx, st, 0, 0, 0, out, known=True, words=False) == "done":
+        return out["removed"]
+    st.inexact_rounds += 1
+    r = _local(st, ctx.denoise, 0)
+    red = _allreduce([r] + _codes(st), st)
+    _raise_codes(ctx, st, red[1:])
+    st.ndistinct -= red[0]
+    st.nelts -= red[0]
+    return red[0]
 
 
 def sharded_count(ctx, st, nchunks):
@@ -382,7 +406,18 @@ def sharded_count(ctx, st, nchunks):
             st.other_points += 1
             out["denoise_rounds"] += 1
             fused = False
-            if hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
+            exact = not os.environ.get("SHK_NO_FUSED_POINT")
+            if exact and hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
+                # the round and the chunks behind the point in one rebuild, the range walk over the single table's layout
+                if _one_pass_point(ctx, st, hi + 1, hi, nchunks - 1, out, known=True) == "done":
+                    fused = True
+                    hi = nchunks - 1
+            if not fused and exact:
+                # the round alone, the same way
+                fused = _one_pass_point(ctx, st, 0, 0, 0, out, known=True, words=False) == "done"
+            if not fused and hi + 1 < nchunks and not os.environ.get("SHK_NO_FUSED_DENOISE"):
+                # (last resort, and SHK_NO_FUSED_POINT: each shard walks its own part from its own first slot -- range-end
+                # singletons next to shard borders may differ from the single table's, st.inexact_rounds counts these)
                 # one pass: drop the singletons and insert the chunks behind the deNoise point; taken when no rank
                 # objects and the trigger is not reached again inside the rest
                 d = _decide(ctx, st, lambda: ctx.stage_try_denoise(hi + 1, nchunks - 1))
@@ -396,7 +431,9 @@ def sharded_count(ctx, st, nchunks):
                     out["new_distinct"] += d.newd
                     fused = True
                     hi = nchunks - 1
+                    st.inexact_rounds += 1
             if not fused:
+                st.inexact_rounds += 1
                 r = _local(st, ctx.denoise, 0)
                 red = _allreduce([r] + [1 if st.pending_rc == -c else 0 for c in range(1, NCODES + 1)], st)
                 for c in range(1, NCODES + 1):
