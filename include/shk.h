@@ -140,8 +140,10 @@ int shk_count_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords, uint
  *   shk_stage_words    copy + partition the routed key words (chunk ids are global)
  *   shk_stage_summary  statistics of inserting the words of chunks [lo, hi]; nothing is written
  *   shk_stage_commit   write them; must follow a summary over exactly [lo, hi]
- *   shk_denoise        one round on this shard (the range walk of CQF_mt.h:888-895 restarts at
- *                      every shard: see DESIGN.md section 6) */
+ *   shk_denoise        one round on this shard alone: its range walk (CQF_mt.h:888-895) starts at the shard's first
+ *                      slot. The sharded driver uses it only as a last resort -- rounds normally go through
+ *                      shk_stage_point_* / shk_stage_round_try below, which continue the walk from shard to shard
+ *                      over the single table's layout */
 typedef struct shk_summary {
   uint64_t new_distinct, added, removed, before;
   uint64_t hist[32];
