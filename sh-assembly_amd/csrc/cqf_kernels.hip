@@ -221,9 +221,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
   static_assert(IMGB <= SHK_WAVE, "one lane per image block in the rank/select step");
   __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
-  __shared__ uint32_t hcnt[SHK_HCAP];   // occurrences in this batch (FUSED: in the chunks <= split)
-  __shared__ uint32_t hcntB[FUSED ? SHK_HCAP : 1];      // FUSED: occurrences in the chunks behind the split
-  __shared__ uint32_t qcnt_i[FUSED ? SHK_REGION : 1];   // FUSED: run length per quotient in the intermediate table
+  // occurrences in this batch; FUSED: 64 bits per key, low word = in the chunks <= split, high word = behind it (one LDS atomic)
+  __shared__ __attribute__((aligned(8))) uint32_t hcnt[FUSED ? 2 * SHK_HCAP : SHK_HCAP];
   __shared__ uint32_t s_added_b;
   __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
   __shared__ uint16_t qoff[SHK_REGION + 2];
@@ -288,8 +287,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
     uint32_t *dst = reinterpret_cast<uint32_t *>(oimg);
     if (!(A.ablate & 64)) for (uint32_t i = tid; i < (nbytes + 3) / 4; i += ngrp) dst[i] = src[i];
-    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; if (FUSED) hcntB[i] = 0; }
-    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) { qcnt[i] = 0; if (FUSED) qcnt_i[i] = 0; }
+    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; if (FUSED) hcnt[SHK_HCAP + i] = 0; }
+    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) qcnt[i] = 0;
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
@@ -362,8 +361,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           }
           if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
           if (FUSED) {
-            atomicAdd(&hcnt[h[u]], (match && bef[u]) ? wgt[u] : 0u);
-            atomicAdd(&hcntB[h[u]], (match && !bef[u]) ? wgt[u] : 0u);
+            const unsigned long long inc = match ? (bef[u] ? (unsigned long long)wgt[u] : (unsigned long long)wgt[u] << 32) : 0ULL;
+            atomicAdd(reinterpret_cast<unsigned long long *>(hcnt) + h[u], inc);
           } else atomicAdd(&hcnt[h[u]], match ? wgt[u] : 0u);
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
@@ -466,8 +465,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // ---- one pass over the quotients: merge old run and new keys -> run length, statistics,
   // and (write modes) the run's encoding staged per lane
   uint32_t my_new = 0, my_removed = 0, my_before = 0;
-  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
-  ShkMP mine_i; mine_i.a = 0; mine_i.b = SHK_NEG_INF;   // FUSED: the same for the intermediate table
+  // (region-relative free-pointer functions: 32-bit arithmetic inside the kernel)
+  ShkMPw mine; mine.a = 0; mine.b = SHK_NEG_INF_W;
+  ShkMPw mine_i; mine_i.a = 0; mine_i.b = SHK_NEG_INF_W;   // FUSED: the same for the intermediate table
+  uint32_t l4i = 0;                // FUSED: my four run lengths in the intermediate table, one byte each
+  bool big_i = false;
   uint32_t st_used = 0;            // staged bytes of this lane
   bool st_over = false;            // a run did not fit: this lane re-merges at placement time
   uint8_t *mystage = stage + tid * SHK_STAGE_STRIDE;
@@ -504,13 +506,13 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       if (eq != curq) {                     // the previous quotient's run is complete
         if (len) {
           qcnt[curq] = len;
-          ShkMP m; m.a = len; m.b = (long long)curq + len;
-          mine = shk_mp_compose(mine, m);
+          ShkMPw m; m.a = (int)len; m.b = (int)(curq + len);
+          mine = shk_mpw_compose(mine, m);
         }
         if (FUSED && ilen) {
-          qcnt_i[curq] = ilen;
-          ShkMP m; m.a = ilen; m.b = (long long)curq + ilen;
-          mine_i = shk_mp_compose(mine_i, m);
+          l4i |= (ilen > 255u ? 255u : ilen) << (8 * (curq - qa)); big_i |= ilen > 255u;
+          ShkMPw m; m.a = (int)ilen; m.b = (int)(curq + ilen);
+          mine_i = shk_mpw_compose(mine_i, m);
         }
         curq = eq; len = 0; ilen = 0;
       }
@@ -533,8 +535,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           } else ohas = false;
         }
         if (take_new) {
-          cb += hcnt[nh]; ca = hcntB[nh];
-          if (A.newchunks && !take_old) hcnt[nh] |= 0x80000000u;   // a key the table has not seen: its first chunk is collected below
+          { const unsigned long long c2 = reinterpret_cast<const unsigned long long *>(hcnt)[nh]; cb += (uint32_t)c2; ca = c2 >> 32; }
+          if (A.newchunks && !take_old) hcnt[2 * nh + 1] = 0x80000000u;   // a key the table has not seen: its first chunk is collected below (the counts are consumed)
           ni++;
           ncomp = NONE;
           if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
@@ -620,35 +622,27 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
     if (len) {
       qcnt[curq] = len;
-      ShkMP m; m.a = len; m.b = (long long)curq + len;
-      mine = shk_mp_compose(mine, m);
+      ShkMPw m; m.a = (int)len; m.b = (int)(curq + len);
+      mine = shk_mpw_compose(mine, m);
     }
     if (FUSED && ilen) {
-      qcnt_i[curq] = ilen;
-      ShkMP m; m.a = ilen; m.b = (long long)curq + ilen;
-      mine_i = shk_mp_compose(mine_i, m);
+      l4i |= (ilen > 255u ? 255u : ilen) << (8 * (curq - qa)); big_i |= ilen > 255u;
+      ShkMPw m; m.a = (int)ilen; m.b = (int)(curq + ilen);
+      mine_i = shk_mpw_compose(mine_i, m);
     }
   }
   SHK_STAMP(4);   // merge pass
   if (FUSED) {
     // the intermediate table's (T, c) and run lengths: what the range walk of the round needs to know about this region
-    ShkMP inc_i = mine_i;
+    ShkMPw inc_i = mine_i;
     for (int d = 1; d < SHK_WAVE; d <<= 1) {
-      ShkMP y;
+      ShkMPw y;
       y.a = __shfl_up(inc_i.a, d);
       y.b = __shfl_up(inc_i.b, d);
-      if (tid >= (unsigned)d) inc_i = shk_mp_compose(y, inc_i);
+      if (tid >= (unsigned)d) inc_i = shk_mpw_compose(y, inc_i);
     }
-    uint32_t l4 = 0;
-    bool big = false;
-#pragma unroll
-    for (uint32_t j = 0; j < SHK_REGION / nthr; j++) {
-      const uint32_t li = qcnt_i[tid * (SHK_REGION / nthr) + j];
-      if (li > 255) big = true;
-      l4 |= (li & 255u) << (8 * j);
-    }
-    reinterpret_cast<uint32_t *>(A.ilens + (size_t)r * SHK_REGION)[tid] = l4;
-    if (__ballot(big) && tid == 0) atomicOr(A.err, SHK_E_FUSED);
+    reinterpret_cast<uint32_t *>(A.ilens + (size_t)r * SHK_REGION)[tid] = l4i;
+    if (__ballot(big_i) && tid == 0) atomicOr(A.err, SHK_E_FUSED);
     if (tid == SHK_WAVE - 1) {
       A.isum[2 * (size_t)r] = fatal ? 0 : (uint32_t)inc_i.a;
       A.isum[2 * (size_t)r + 1] = (!fatal && inc_i.b > 0) ? (uint32_t)inc_i.b : 0;
@@ -656,18 +650,18 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
   }
   // wave scan of the free-pointer functions (lane order = quotient order)
-  ShkMP incl = mine;
+  ShkMPw incl = mine;
   for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    ShkMP y;
+    ShkMPw y;
     y.a = __shfl_up(incl.a, d);
     y.b = __shfl_up(incl.b, d);
-    if (tid >= (unsigned)d) incl = shk_mp_compose(y, incl);
+    if (tid >= (unsigned)d) incl = shk_mpw_compose(y, incl);
   }
-  ShkMP tot, pre;
+  ShkMP tot, pre;          // (64-bit from here on: the placement works with absolute slots)
   tot.a = __shfl(incl.a, SHK_WAVE - 1);
-  tot.b = __shfl(incl.b, SHK_WAVE - 1);
+  { const int tb = __shfl(incl.b, SHK_WAVE - 1); tot.b = tb > 0 ? tb : SHK_NEG_INF; }
   pre.a = __shfl_up(incl.a, 1);
-  pre.b = __shfl_up(incl.b, 1);
+  { const int pb = __shfl_up(incl.b, 1); pre.b = pb > 0 ? pb : SHK_NEG_INF; }
   if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
 
   // per-region statistics (summed later by k_region_scan_c / k_stats_reduce: no same-address atomics)
@@ -693,7 +687,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < nlist; i0 += SHK_WAVE) {     // nidx[0, nlist) = every hash slot in use
       const uint32_t h = i0 + tid < nlist ? nidx[i0 + tid] : 0;
-      const bool f = i0 + tid < nlist && (hcnt[h] >> 31);
+      const bool f = i0 + tid < nlist && (hcnt[FUSED ? 2 * h + 1 : h] >> 31);
       const unsigned long long m = __ballot(f);
       if (f) nc[base + (uint32_t)__popcll(m & ((1ULL << tid) - 1))] = (uint16_t)(hkey[h] & (SHK_MAX_CHUNKS - 1));
       base += (uint32_t)__popcll(m);

@@ -260,12 +260,13 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
                              const uint64_t *nreads_p, const uint16_t *rd_chunk,
                              uint32_t chunk_first, uint32_t chunk_mul, const uint64_t *key_base, uint32_t k, uint32_t hb,
                              uint64_t *words, uint64_t cap, uint32_t *err, uint64_t *hist0, uint32_t dig_shift, uint32_t dig_bits,
-                             uint64_t q_lo) {
+                             uint64_t q_lo, uint32_t ng_log2) {
   // hist0 != null: also count the keys per first partition digit (digit = (region >> dig_shift) & (2^dig_bits - 1)),
-  // which saves the partition its first pass over the keys
+  // which saves the partition its first pass over the keys; with ng_log2 > 0 per (digit, window group of the key's position):
+  // ShkRpLevel::ng_log2 (dig_bits + ng_log2 <= 10)
   __shared__ uint32_t lh0[1024];
   if (hist0) {
-    for (uint32_t d = threadIdx.x; d < (1u << dig_bits); d += blockDim.x) lh0[d] = 0;
+    for (uint32_t d = threadIdx.x; d < (1u << (dig_bits + ng_log2)); d += blockDim.x) lh0[d] = 0;
     __syncthreads();
   }
   __shared__ uint64_t ringG[SHK_HASH_WAVES][256];  // launched with at most SHK_HASH_WAVES waves per group
@@ -347,7 +348,7 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
           words[out + p] = (hv & mask) | chunk_tag;
           if (hist0) {   // the digit exactly as k_rp_scatter computes it (shk_word_region)
             const uint32_t reg = (uint32_t)((((hv & mask) >> 8) - q_lo) >> SHK_REGION_LOG2);
-            atomicAdd(&lh0[(reg >> dig_shift) & ((1u << dig_bits) - 1)], 1u);
+            atomicAdd(&lh0[(((reg >> dig_shift) & ((1u << dig_bits) - 1)) << ng_log2) | ((uint32_t)((out + p) >> 12) & ((1u << ng_log2) - 1))], 1u);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -360,7 +361,7 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
   }
   if (hist0) {
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < (1u << dig_bits); d += blockDim.x)
+    for (uint32_t d = threadIdx.x; d < (1u << (dig_bits + ng_log2)); d += blockDim.x)
       if (lh0[d]) atomicAdd((unsigned long long *)&hist0[d], (unsigned long long)lh0[d]);
   }
 }

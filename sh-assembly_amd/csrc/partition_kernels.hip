@@ -20,6 +20,12 @@ struct ShkRpLevel {
   uint64_t q_lo;      // first quotient this context owns (multi-GPU shards)
   uint64_t nslots;    // quotients this context owns
   uint32_t out32;     // 1 (last level): write 32-bit records (quotient in region << 8 | remainder) << SHK_CHUNK_BITS | chunk
+  uint32_t ablate;    // diagnostics only (SHK_RP_ABLATE): 1 = no reservation atomics, all windows write the same few KB per digit (results invalid)
+  uint32_t ng_log2;   // first level only: every digit's bucket is laid out as 2^ng_log2 sub-buckets, one per window group
+                      // (window index mod 2^ng_log2), each with its own cursor, so that the windows of a batch do not all
+                      // reserve from the same P addresses. Measured on 832 M keys: the scatter itself is unchanged (its
+                      // first level stays at 4.7 ms against 3.2 for the second: not the atomics), the hash kernel's
+                      // histogram flush gets 5 % off that kernel
 };
 
 __device__ __forceinline__ uint32_t shk_word_region(uint64_t w, uint32_t hb, uint64_t q_lo) {
@@ -112,7 +118,7 @@ __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint
     const uint64_t lo = bucket_base[b] > wstart ? bucket_base[b] : wstart;
     const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
     if (hi <= lo) continue;
-    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
+    for (uint32_t d = threadIdx.x; d < (P << lv.ng_log2); d += blockDim.x) lh[d] = 0;
     __syncthreads();
     // four loads in flight per thread
     for (uint64_t i0 = lo; i0 < hi; i0 += 4ull * blockDim.x) {
@@ -125,14 +131,24 @@ __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
-        if (i < hi) atomicAdd(&lh[(shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1)], 1u);
+        if (i < hi) {
+          const uint32_t dg = (shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
+          const uint32_t grp = (uint32_t)(i / SHK_RP_TILE) & ((1u << lv.ng_log2) - 1);     // the scatter window this key lies in
+          atomicAdd(&lh[(dg << lv.ng_log2) | grp], 1u);
+        }
       }
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
-      if (lh[d]) atomicAdd((unsigned long long *)&hist[(uint64_t)b * P + d], (unsigned long long)lh[d]);
+    for (uint32_t d = threadIdx.x; d < (P << lv.ng_log2); d += blockDim.x)
+      if (lh[d]) atomicAdd((unsigned long long *)&hist[(((uint64_t)b * P) << lv.ng_log2) + d], (unsigned long long)lh[d]);
     __syncthreads();
   }
+}
+
+// bucket bases of the next level from the scanned sub-bucket bases of a grouped first level: base[d] = sub[d << ng_log2]
+__global__ void k_rp_group_bases(const uint64_t *sub, uint32_t nd, uint32_t ng_log2, uint64_t *base) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d <= nd) base[d] = sub[(uint64_t)d << ng_log2];
 }
 
 // cursor[b*P+d] starts at the scanned base of (b,d) and is advanced by reservations.
@@ -189,7 +205,8 @@ __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *i
       uint32_t ex = shk_block_exscan(v, &tot, scratch);
       if (d < P) {
         lbase[d] = carry + ex;
-        gbase[d] = v ? atomicAdd((unsigned long long *)&cursor[(uint64_t)b * P + d], (unsigned long long)v) : 0;
+        if (lv.ablate & 1) gbase[d] = cursor[((uint64_t)b * P + d) << lv.ng_log2] + (uint64_t)(blockIdx.x % 1024) * 24;
+        else gbase[d] = v ? atomicAdd((unsigned long long *)&cursor[((((uint64_t)b * P) + d) << lv.ng_log2) | (blockIdx.x & ((1u << lv.ng_log2) - 1))], (unsigned long long)v) : 0;
       }
       carry += tot;
     }

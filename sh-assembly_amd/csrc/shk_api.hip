@@ -66,7 +66,8 @@ struct shk_ctx {
   uint64_t *d_words[2];
   uint64_t *d_scalars;          // [0] nreads, [1] nwords, [2] scan total scratch, [3] marks
   uint64_t *d_block_sums;
-  uint64_t *d_hist[4];          // per level: nbuckets*P
+  uint64_t *d_hist[4];          // per level: nbuckets*P (first level: times its window groups)
+  uint64_t *d_base_sub;         // first level with window groups: scanned bases of the (digit, group) sub-buckets
   uint64_t *d_base[5];          // base[l]: bucket bases entering level l (base[nlevels] = region_base)
   uint64_t *d_cursor;
   uint32_t *d_tfb;
@@ -205,10 +206,12 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
       uint32_t bits = (left + (c->nlevels - l) - 1) / (c->nlevels - l);
       left -= bits;
       c->lv[l].shift = left; c->lv[l].bits = bits; c->lv[l].nbuckets = nb; c->lv[l].hb = cfg->hb; c->lv[l].q_lo = c->q_lo;
-      c->lv[l].nslots = c->nslots; c->lv[l].out32 = 0;
+      c->lv[l].nslots = c->nslots; c->lv[l].out32 = 0; c->lv[l].ablate = 0; c->lv[l].ng_log2 = 0;
       nb <<= bits;
     }
     c->lv[c->nlevels - 1].out32 = 1;
+    // first level: one cursor per (digit, window group) instead of one per digit (ShkRpLevel::ng_log2)
+    if (c->lv[0].bits >= 2 && c->lv[0].bits <= 7 && !getenv("SHK_RP_NO_GROUPS")) c->lv[0].ng_log2 = 3;
   }
   c->threads = cfg->threads_per_group ? cfg->threads_per_group : 512;
   if (c->threads < 64 || c->threads > 1024 || (c->threads & (c->threads - 1))) { delete c; return SHK_ERR_ARG; }
@@ -240,10 +243,12 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
     if (dmalloc(&c->d_base[0], 2)) return SHK_ERR_HIP;
     for (uint32_t l = 0; l < c->nlevels; l++) {
       uint64_t n = nb << c->lv[l].bits;
-      if (dmalloc(&c->d_hist[l], n + 1) || dmalloc(&c->d_base[l + 1], n + 2)) return SHK_ERR_HIP;
+      if (dmalloc(&c->d_hist[l], (n << c->lv[l].ng_log2) + 1) || dmalloc(&c->d_base[l + 1], n + 2)) return SHK_ERR_HIP;
+      if (l == 0 && dmalloc(&c->d_base_sub, (n << c->lv[0].ng_log2) + 2)) return SHK_ERR_HIP;
       nb = n;
     }
-    if (dmalloc(&c->d_cursor, nb + 2)) return SHK_ERR_HIP;
+    { const uint64_t first = (1ULL << (c->lv[0].bits + c->lv[0].ng_log2));
+      if (dmalloc(&c->d_cursor, (nb > first ? nb : first) + 2)) return SHK_ERR_HIP; }
   }
   if (dmalloc(&c->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
   if (dmalloc(&c->d_summary, SHK_SUM_STRIDE * (uint64_t)c->nregions + 8)) return SHK_ERR_HIP;
@@ -294,7 +299,7 @@ extern "C" void shk_destroy(shk_ctx *c) {
   hipFree(c->d_text); hipFree(c->d_chunk_off); hipFree(c->d_chunk_len); hipFree(c->d_nlines); hipFree(c->d_reads_base);
   hipFree(c->d_rd_start); hipFree(c->d_rd_end); hipFree(c->d_rd_chunk); hipFree(c->d_nkeys); hipFree(c->d_key_base); hipFree(c->d_scalars);
   hipFree(c->d_block_sums);
-  hipFree(c->d_base[0]);
+  hipFree(c->d_base[0]); hipFree(c->d_base_sub);
   for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(c->d_hist[l]); hipFree(c->d_base[l + 1]); }
   if (c->d_isum) { hipFree(c->d_isum); hipFree(c->d_ilens); hipFree(c->d_fin_i); hipFree(c->d_prot); }
   hipFree(c->d_spill); hipFree(c->d_over_list); if (c->d_newchunks) { hipFree(c->d_newchunks); hipFree(c->d_chist); hipHostFree(c->h_chist); } hipFree(c->d_cursor); hipFree(c->d_tfb); hipFree(c->d_summary); hipFree(c->d_lb_agg); hipFree(c->d_lb_incl); hipFree(c->d_tile_a); hipFree(c->d_tile_b); hipFree(c->d_tile_f); hipFree(c->d_counters); hipFree(c->d_err);
@@ -365,7 +370,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
                       const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul, bool hist0 = false) {
   // chunk i of this call is labelled chunk_first + i * chunk_mul; hist0: the hash kernel also fills the first partition
   // level's histogram (d_hist[0]), see partition_stage
-  if (hist0) HIPCHK(hipMemsetAsync(c->d_hist[0], 0, (1ULL << c->lv[0].bits) * 8, c->stream));
+  if (hist0) HIPCHK(hipMemsetAsync(c->d_hist[0], 0, (1ULL << (c->lv[0].bits + c->lv[0].ng_log2)) * 8, c->stream));
   if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
   const uint8_t *dtext;
   uint64_t nreads;
@@ -382,7 +387,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
     const uint32_t ht = c->threads < SHK_HASH_WAVES * SHK_WAVE ? c->threads : SHK_HASH_WAVES * SHK_WAVE;
     hipLaunchKernelGGL(k_hash_reads, dim3(groups * (c->threads / ht)), dim3(ht), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
                        c->d_scalars + 0, c->d_rd_chunk, chunk_first, chunk_mul, c->d_key_base, c->cfg.k, c->cfg.hb,
-                       c->d_words[0], c->cfg.max_batch_keys, c->d_err, hist0 ? c->d_hist[0] : nullptr, c->lv[0].shift, c->lv[0].bits, c->q_lo); }
+                       c->d_words[0], c->cfg.max_batch_keys, c->d_err, hist0 ? c->d_hist[0] : nullptr, c->lv[0].shift, c->lv[0].bits, c->q_lo, c->lv[0].ng_log2); }
   HIPCHK(hipGetLastError());
   return SHK_OK;
 }
@@ -401,15 +406,26 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
     { ProfScope ps(c, KP_RP_PREP);
       hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
-      if (!(l == 0 && hist0_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, nb * P * 8, c->stream)); }
+      if (!(l == 0 && hist0_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream)); }
     if (!(l == 0 && hist0_ready)) { ProfScope ps(c, KP_RP_HIST);
       const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
       hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
-    if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
-    HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (c->lv[l].ng_log2) {
+      // (first level only: nb = 1) sub-buckets in (digit, group) order; the next level's buckets are the digits
+      const uint32_t ng = c->lv[l].ng_log2;
+      if (run_scan<uint64_t>(c, c->d_hist[l], P << ng, nullptr, c->d_base_sub)) return SHK_ERR_HIP;
+      HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base_sub, (P << ng) * 8, hipMemcpyDeviceToDevice, c->stream));
+      ProfScope ps(c, KP_RP_PREP);
+      hipLaunchKernelGGL(k_rp_group_bases, dim3((uint32_t)(P / 256 + 1)), dim3(256), 0, c->stream, c->d_base_sub, (uint32_t)P, ng, c->d_base[l + 1]);
+    } else {
+      if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
+      HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
     { ProfScope ps(c, KP_RP_SCATTER);
+      ShkRpLevel lvl = c->lv[l];
+      if (const char *e = getenv("SHK_RP_ABLATE")) lvl.ablate = (uint32_t)atoi(e);
       hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
-                         c->d_base[l], c->d_tfb, c->lv[l], c->d_cursor, c->d_err); }
+                         c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err); }
     cur ^= 1;
     in = c->d_words[cur];
   }
@@ -1234,7 +1250,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   // one partition level over the WHOLE filter's regions: digit = owner
   ShkRpLevel lv;
   lv.shift = (c->cfg.qb - SHK_REGION_LOG2) - lg; lv.bits = lg; lv.nbuckets = 1; lv.hb = c->cfg.hb; lv.q_lo = 0;
-  lv.nslots = ~0ULL; lv.out32 = 0;
+  lv.nslots = ~0ULL; lv.out32 = 0; lv.ablate = 0; lv.ng_log2 = 0;
   c->h_pinned[43] = nwords;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
   const uint64_t *n_p = c->d_scalars + 1;

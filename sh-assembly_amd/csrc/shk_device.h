@@ -156,6 +156,20 @@ __device__ __forceinline__ long long shk_mp_apply(ShkMP m, long long f) {
   return t > m.b ? t : m.b;
 }
 
+// the same in 32 bits, for values relative to a region start (k_region_merge: a <= slots of one region's runs, b <= 256 + a)
+#define SHK_NEG_INF_W (-(1 << 28))
+struct ShkMPw {
+  int a, b;
+};
+__device__ __forceinline__ ShkMPw shk_mpw_compose(ShkMPw first, ShkMPw second) {
+  ShkMPw r;
+  r.a = first.a + second.a;
+  const int t = first.b + second.a;
+  r.b = t > second.b ? t : second.b;
+  if (r.b < SHK_NEG_INF_W) r.b = SHK_NEG_INF_W;
+  return r;
+}
+
 // ---- bytes of the packed block image (global or LDS): unaligned little-endian access
 __device__ __forceinline__ uint64_t shk_ld64(const uint8_t *p) {
   uint64_t v = 0;
