@@ -1368,7 +1368,11 @@ extern "C" int shk_stage_accept(shk_ctx *c, const shk_summary *s) {
 // s->new_distinct counts dropped keys that reappear in [lo, hi] as new. Needs the spill scheme (default).
 extern "C" int shk_stage_try_denoise(shk_ctx *c, uint32_t lo, uint32_t hi, shk_summary *out) {
   if (!c || !out || hi < lo || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;
-  if (!c->use_spill) return SHK_ERR_ARG;
+  if (!c->use_spill) {        // (another rebuild scheme was asked for: the caller runs shk_denoise and goes on)
+    memset(out, 0, sizeof(*out));
+    out->err_bits = SHK_E_FUSED;
+    return SHK_OK;
+  }
   HIPCHK(hipSetDevice(c->dev));
   uint64_t ml = c->cfg.min_denoise_len ? c->cfg.min_denoise_len : (1ULL << 20);
   { ProfScope ps(c, KP_MARKS);
@@ -1406,11 +1410,11 @@ extern "C" int shk_stage_sample(shk_ctx *c, uint32_t lo, uint32_t hi, uint64_t *
 
 extern "C" int shk_stage_point_try(shk_ctx *c, uint32_t lo, uint32_t split, uint32_t hi, shk_point *out) {
   if (!c || !out || hi < lo || split + 1 < lo || split > hi || hi >= SHK_MAX_CHUNKS) return SHK_ERR_ARG;   // (split = lo - 1: the round comes first)
-  if (!c->use_spill || c->single_ok) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   c->pt_valid = 0;
   memset(out, 0, sizeof(*out));
-  if (c->big_image) { out->err_bits = SHK_E_FUSED; return SHK_OK; }     // (the retry image is not instantiated for this pass)
+  // (needs the spill scheme; the retry image is not instantiated for this pass: the caller takes another path)
+  if (c->big_image || !c->use_spill || c->single_ok) { out->err_bits = SHK_E_FUSED; return SHK_OK; }
   PointOut po;
   int rc = point_try(c, c->d_words[c->staged], lo, split, hi, true, &po);
   prof_collect(c);
@@ -1424,11 +1428,11 @@ extern "C" int shk_stage_point_try(shk_ctx *c, uint32_t lo, uint32_t split, uint
 // a deNoise round on its own (no words), taken the same way: the range walk then runs over the single table's layout
 extern "C" int shk_stage_round_try(shk_ctx *c, shk_point *out) {
   if (!c || !out) return SHK_ERR_ARG;
-  if (!c->use_spill || c->single_ok) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   c->pt_valid = 0;
   memset(out, 0, sizeof(*out));
-  if (c->big_image) { out->err_bits = SHK_E_FUSED; return SHK_OK; }
+  // (needs the spill scheme; the retry image is not instantiated for this pass: the caller takes another path)
+  if (c->big_image || !c->use_spill || c->single_ok) { out->err_bits = SHK_E_FUSED; return SHK_OK; }
   PointOut po;
   int rc = point_try(c, nullptr, 0, 0, 0, false, &po);
   prof_collect(c);

@@ -51,6 +51,13 @@ def main():
         # sampled location of the deNoise point (read at context creation): off, or every 2nd / 4th / 8th region -- on these
         # small tables the guess is often wrong, which is the point
         os.environ["SHK_SAMPLE_STRIDE"] = str(rnd.choice([0, 2, 2, 4, 8]))
+        # the rebuild schemes behind the default one (fallbacks and diagnostics) must stay byte-exact too: the library reads
+        # these switches when a context is created / a pass is planned
+        for v in ("SHK_SINGLE", "SHK_TWO_LAUNCH", "SHK_COARSE_HIST", "SHK_NO_FUSED_POINT", "SHK_RP_NO_GROUPS"):
+            os.environ.pop(v, None)
+        scheme = rnd.choice([None] * 5 + ["SHK_SINGLE", "SHK_TWO_LAUNCH", "SHK_COARSE_HIST", "SHK_NO_FUSED_POINT", "SHK_RP_NO_GROUPS"])
+        if scheme:
+            os.environ[scheme] = "1"
         if args.sharded:
             ctx = shk.Context(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L + 64,
                               shard_index=0, num_shards=1, max_level_bits=mlb)
@@ -81,7 +88,7 @@ def main():
             print("case", case, "error", e)
         if not ok:
             bad += 1
-            print("MISMATCH case", case, dict(qb=qb, k=k, L=L, nreads=nreads, G=G, err=err, per=per, nd=nd, trig=trig, endd=endd, ml=ml,
+            print("MISMATCH case", case, scheme, dict(qb=qb, k=k, L=L, nreads=nreads, G=G, err=err, per=per, nd=nd, trig=trig, endd=endd, ml=ml,
                                               ncalls=ncalls, rounds=(rounds, orounds), removed=(removed, oremoved)))
         ctx.close()
         q.free()
