@@ -333,7 +333,8 @@ def main():
         traffic, traffic_src, step_traffic = None, None, None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            pk = {"k_region_merge<spill>": "k_region_merge<3, 24, false>", "k_region_place": "k_region_place<24>"}.get(name, name)
+            pk = {"k_region_merge<spill>": "k_region_merge<3, 24, false>", "k_region_merge<fused>": "k_region_merge<3, 24, true>",
+                  "k_region_merge<sample>": "k_region_merge<0, 24, false>", "k_region_place": "k_region_place<24>"}.get(name, name)
             if default_workload and pk in pt["kernels"]:
                 traffic = pt["kernels"][pk]["fetch_bytes_per_launch"] + pt["kernels"][pk]["write_bytes_per_launch"]
                 traffic_src = pt["source"]
@@ -365,7 +366,7 @@ def main():
             # the path-level figure; `traffic` = measured HBM bytes per step (separate --pmc passes)
             "roofline": {"bound": "hbm", "scope": "whole insert path: hash + partition + rebuild + deNoise rounds",
                          "achieved": path_bytes / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": path_bytes / dt / HBM_PEAK, "traffic": step_traffic, "traffic_unit": "bytes per step without a deNoise point (measured, all kernels; profiles/pmc_traffic.json)",
+                         "frac": path_bytes / dt / HBM_PEAK, "traffic": step_traffic, "traffic_unit": "bytes per step, mean of the build's first 3 steps, one with a deNoise point (measured, all kernels; profiles/pmc_traffic.json)",
                          "formula": "(kmers*179 + rounds*2*table_bytes) / t / 8e12 (SURVEY.md 8d)",
                          "algorithmic_bytes_per_kmer": ALGO_BYTES_PER_KMER, "table_bytes": table_bytes},
             # the kernel with the most device time, on its MEASURED bytes (no algorithmic figure applies to one stage)

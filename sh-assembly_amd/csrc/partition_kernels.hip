@@ -156,9 +156,7 @@ __global__ void k_rp_group_bases(const uint64_t *sub, uint32_t nd, uint32_t ng_l
 // registers; ONE LDS atomic per key yields both the digit count and the key's rank inside
 // its digit (the order of keys inside a bucket is free: the rebuild folds them into a hash);
 // after the scan the keys are staged digit by digit in LDS and leave as contiguous runs.
-#ifndef SHK_RP_THREADS
-#define SHK_RP_THREADS 512       // (the CPU emulator build of the tests lowers it: every thread is an OS thread there)
-#endif
+#define SHK_RP_THREADS 512
 #define SHK_RP_KPT (SHK_RP_TILE / SHK_RP_THREADS)
 __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
                                                                const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,

@@ -6,21 +6,23 @@
 // the CPU test suite, under valgrind/ASan if wanted, before spending GPU time. It is never
 // loaded by the product path: sh-assembly_amd/ only ever opens libshk.so built by hipcc.
 //
-// Model: workgroups run one after another; every thread of a workgroup is an OS thread;
-// __syncthreads is a barrier; a wave is 64 consecutive threads that exchange values
-// through a per-wave mailbox guarded by a per-wave barrier. `__shared__` becomes `static`
-// (one workgroup is alive at a time).
+// Model: workgroups run one after another; every thread of a workgroup is a FIBER (ucontext) of
+// the calling OS thread, scheduled round robin; a fiber runs until it has to wait at a barrier
+// (__syncthreads, or the per-wave barrier inside a wave collective) and then hands the CPU to
+// the next one -- no OS threads, no futexes: the suite spends its time in the kernels' code.
+// A wave is 64 consecutive threads that exchange values through a per-wave mailbox. Threads
+// that have left the kernel no longer take part in barriers (waves may exit early on the GPU
+// too); a collective that not all live lanes of a wave reach is a deadlock here as it would be
+// undefined there: the scheduler aborts with a message when every live fiber is waiting.
+// `__shared__` becomes `static` (one workgroup is alive at a time).
 #pragma once
-#include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include <algorithm>
-#include <barrier>
 #include <functional>
-#include <thread>
 #include <vector>
 
 #define __global__
@@ -47,23 +49,25 @@ enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 enum { hipHostMallocDefault = 0 };
 
+// a barrier among fibers: the last live member to arrive opens the next generation; waiting = yielding
+struct EmuBarrier { unsigned live, arrived, generation; };
+void emu_barrier_wait(EmuBarrier *b);
 // two mailboxes used alternately: one barrier per collective is enough (a lane can only overwrite a box two
 // collectives later, i.e. after a barrier every reader of that box has already passed)
-struct EmuWave { pthread_barrier_t bar; uint64_t box[2][64]; };
+struct EmuWave { EmuBarrier bar; uint64_t box[2][64]; };
 extern thread_local unsigned emu_phase;
-// the workgroup barrier drops threads that have left the kernel (waves may exit early on the GPU too)
-struct EmuBlock { std::barrier<> *bar; EmuWave waves[16]; };
+struct EmuBlock { EmuBarrier bar; EmuWave waves[16]; };
 extern thread_local EmuBlock *emu_block;
 
-static inline void __syncthreads() { emu_block->bar->arrive_and_wait(); }
+static inline void __syncthreads() { emu_barrier_wait(&emu_block->bar); }
 static inline EmuWave *emu_wave() { return &emu_block->waves[threadIdx.x / 64]; }
-static inline void emu_wave_barrier() { pthread_barrier_wait(&emu_wave()->bar); }
+static inline void emu_wave_barrier() { emu_barrier_wait(&emu_wave()->bar); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
-#define __builtin_amdgcn_s_sleep(n) sched_yield()
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ULL
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
@@ -74,7 +78,7 @@ template <typename T> static inline T emu_xchg(T v, int src_lane, bool valid) {
   memcpy(&raw, &v, sizeof(T));
   const unsigned ph = emu_phase++ & 1;
   w->box[ph][threadIdx.x & 63] = raw;
-  pthread_barrier_wait(&w->bar);
+  emu_barrier_wait(&w->bar);
   uint64_t got = valid ? w->box[ph][src_lane & 63] : raw;
   T out;
   memcpy(&out, &got, sizeof(T));
@@ -109,7 +113,7 @@ static inline unsigned long long __ballot(int pred) {
   EmuWave *w = emu_wave();
   const unsigned ph = emu_phase++ & 1;
   w->box[ph][threadIdx.x & 63] = pred ? 1 : 0;
-  pthread_barrier_wait(&w->bar);
+  emu_barrier_wait(&w->bar);
   unsigned long long m = 0;
   for (int i = 0; i < 64; i++) m |= (unsigned long long)(w->box[ph][i] & 1) << i;
   return m;

@@ -1,11 +1,12 @@
 """CPU tests of the kernel LOGIC: the unmodified sources of sh-assembly_amd/csrc compiled
-with g++ against tests/emu/hip/hip_runtime.h (workgroups as OS threads, waves of 64 with
-barrier-backed shuffles) and driven through the same C ABI. These run without a GPU; the
-real parity tests are tests/test_gpu_parity.py (-m gpu) on libshk.so built by hipcc.
-Sizes are tiny because every thread of a workgroup is an OS thread here."""
+with g++ against tests/emu/hip/hip_runtime.h (every GPU thread a fiber, waves of 64 with
+barrier-backed shuffles, 512-thread workgroups as on the GPU) and driven through the same C ABI.
+These run without a GPU; the real parity tests are tests/test_gpu_parity.py (-m gpu) on libshk.so
+built by hipcc. Sizes are small: workgroups run one after another on one core."""
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -401,7 +402,7 @@ def test_counted_insert_dump_merge_shards(shk):
     def mk_shard(qb, s, n):
         return _ctx(shk, qb=qb, k=21, max_batch_keys=1 << 14, shard_index=s, num_shards=n)
     rng = random.Random(11)
-    # (few and small cases: every workgroup thread is an OS thread here; tests/test_gpu_parity.py runs the full set)
+    # (a few small cases; tests/test_gpu_parity.py runs the full set)
     F.check_counted_and_dump(mk, 10, F.pairs(rng, 10, 120, 1 << 14, cluster=(700, 90)))      # a long cluster: offsets saturate
     F.check_counted_and_dump(mk, 10, F.pairs(rng, 10, 60, 300, cluster=(1000, 24)), batches=2)  # runs spill into the tail
     a = F.pairs(rng, 10, 100, 400, cluster=(300, 60))
@@ -460,3 +461,17 @@ def test_unitig_set_invariants(shk, tmp_path, mark):
     assert any(len(x) == 70 + k - 1 and x[-(k - 1):] == x[:k - 1] for x in seqs)      # the plasmid came out as one pure circle
     ctx.close()
     q.free()
+
+
+@pytest.mark.parametrize("flow", ["single", "sharded"])
+def test_randomised_configurations_on_the_emulator(shk, flow):
+    """tools/fuzz_gpu.py on the CPU build of the kernels: random filter sizes, k, read mixes, chunking, batching, deNoise
+    trigger / rounds / range length, sampled-guess strides and rebuild schemes; table bytes, header, counters, rounds and
+    removed counts equal the oracle's t = 1 build in every case (the GPU suite runs hundreds of these per round)"""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--emu", "--max-qb", "13", "--cases", "12", "--seed", "7"]
+    if flow == "sharded":
+        cmd += ["--sharded"]
+    env = dict(os.environ, MASTER_PORT=str(29800 + os.getpid() % 150))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert "12 cases, 0 mismatches" in r.stdout

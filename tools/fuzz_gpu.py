@@ -10,7 +10,10 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--sharded", action="store_true", help="drive the collective flow (shk/dist.py) with one rank over RCCL")
+    ap.add_argument("--emu", action="store_true", help="run the kernels in the CPU emulator build (tests/emu/libshk_emu.so; one rank over gloo with --sharded)")
+    ap.add_argument("--max-qb", type=int, default=17)
     args = ap.parse_args()
+    lib = os.path.join(ROOT, "tests", "emu", "libshk_emu.so") if args.emu else None
     import torch  # noqa: F401  (torch's HIP runtime first)
     import shk, synth
     from fastq_util import chunks_by_records, oracle_t1, oracle_header
@@ -18,13 +21,13 @@ def main():
         import torch.distributed as dist
         from shk import dist as shkdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=0, world_size=1)
-        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo" if args.emu else "nccl", rank=0, world_size=1)
+        dev = torch.device("cpu" if args.emu else "cuda:0")
     rnd = random.Random(args.seed)
     bad = 0
     t0 = time.time()
     for case in range(args.cases):
-        qb = rnd.choice([11, 12, 13, 14, 15, 16, 17])
+        qb = rnd.choice([q for q in (11, 12, 13, 14, 15, 16, 17) if q <= args.max_qb])
         k = rnd.choice([21, 28, 31, 47, 63, 64, 65, 100])
         L = rnd.choice([max(k + 5, 60), 100, 150])
         cap = int((1 << qb) * 0.45)
@@ -60,11 +63,11 @@ def main():
             os.environ[scheme] = "1"
         if args.sharded:
             ctx = shk.Context(qb=qb, k=k, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=nreads * L + 64,
-                              shard_index=0, num_shards=1, max_level_bits=mlb)
+                              shard_index=0, num_shards=1, max_level_bits=mlb, lib_path=lib)
             sst = shkdist.ShardState(trig, nd, dev)
         else:
             ctx = shk.Context(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024,
-                              max_batch_keys=nreads * L + 64, max_level_bits=mlb)
+                              max_batch_keys=nreads * L + 64, max_level_bits=mlb, lib_path=lib)
         ncalls = rnd.choice([1, 2, 3, len(offs)])
         step = max(1, (len(offs) + ncalls - 1) // ncalls)
         rounds = removed = 0
