@@ -1,6 +1,7 @@
-# CPU-only sanitizer build of the emulated kernels (never shipped to the GPU box: see .gpurunignore)
-include $(dir $(abspath $(lastword $(MAKEFILE_LIST))))Makefile
-# same thing under AddressSanitizer (static LDS arrays and heap "device" buffers are checked)
-$(HERE)libshk_emu_asan.so: $(SRC)/shk_api.hip $(SRC)/kmer_kernels.hip $(SRC)/partition_kernels.hip $(SRC)/cqf_kernels.hip $(SRC)/shk_device.h $(HERE)hip/hip_runtime.h $(HERE)emu_runtime.cpp $(HERE)../../include/shk.h
-	g++ -std=c++20 -O1 -g -fsanitize=address -fno-omit-frame-pointer -fPIC -shared -w -I$(HERE) -x c++ $(SRC)/shk_api.hip $(HERE)emu_runtime.cpp -o $@ -lpthread
-asan: $(HERE)libshk_emu_asan.so
+# TEST INFRASTRUCTURE ONLY: the emulator build under AddressSanitizer (CPU). GPU sanitizer builds are not allowed on the
+# pool, so this file (and tools/asan_emu.sh) stays off the GPU boxes: both are listed in .gpurunignore.
+#   make -C tests/emu -f asan.mk && tools/asan_emu.sh
+HERE := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+SRC  := $(HERE)../../sh-assembly_amd/csrc
+$(HERE)libshk_emu_asan.so: $(SRC)/shk_api.hip $(SRC)/kmer_kernels.hip $(SRC)/partition_kernels.hip $(SRC)/cqf_kernels.hip $(SRC)/merge2_kernels.hip $(SRC)/walk_kernels.hip $(SRC)/unitig_kernels.hip $(SRC)/shk_device.h $(HERE)hip/hip_runtime.h $(HERE)emu_runtime.cpp $(HERE)../../include/shk.h
+	g++ -std=c++20 -O1 -g -fsanitize=address -fno-omit-frame-pointer -fPIC -shared -Wno-unknown-pragmas -I$(HERE) -x c++ $(SRC)/shk_api.hip $(HERE)emu_runtime.cpp -o $@ -lpthread

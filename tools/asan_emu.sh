@@ -3,7 +3,7 @@
 # The sanitized library takes the place of tests/emu/libshk_emu.so for the duration of the run.
 set -e
 cd "$(dirname "$0")/.."
-make -s -C tests/emu && make -s -C tests/emu asan
+make -s -C tests/emu && make -s -C tests/emu -f asan.mk
 cp tests/emu/libshk_emu.so /tmp/libshk_emu_plain.so
 trap 'cp /tmp/libshk_emu_plain.so tests/emu/libshk_emu.so' EXIT
 cp tests/emu/libshk_emu_asan.so tests/emu/libshk_emu.so && touch tests/emu/libshk_emu.so
