@@ -515,6 +515,12 @@ class Exchange:
         allc = allc.view(world, world).tolist()
         rc = [allc[p][rank] for p in range(world)]
         mx = max(max(row) for row in allc)
+        # every rank sees every bin size: a shard that would receive more than it can stage fails on ALL ranks here
+        # (contexts of one job are created alike), not on its own rank inside a collective the others then wait in
+        cap = int(ctx.cfg.max_batch_keys)
+        worst = max(sum(allc[p][r] for p in range(world)) for r in range(world))
+        if worst > cap:
+            raise ShkError(-7, "a shard would receive %d key words, more than max_batch_keys (%d)" % (worst, cap))
         self.recv = _recv_buffer(ctx, sum(rc), device)
         soff = [sum(sc[:p]) for p in range(world)]
         roff = [sum(rc[:p]) for p in range(world)]
