@@ -377,58 +377,64 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   if (my_added) atomicAdd(&s_added, my_added);
   if (FUSED && my_added_b) atomicAdd(&s_added_b, my_added_b);
   __syncthreads();
-  // the helper waves are done: one wave carries on (its barriers below are wave-local)
-  if (tid >= nthr) return;
+  SHK_STAMP(1);   // key folding
+  // Two things are left to prepare before the merge pass, and they do not depend on each other: the structure of the
+  // OLD runs (rank/select over the staged blocks) and the grouping of the NEW keys by quotient. The second wave of the
+  // group takes the first while the first wave does the second (a group of one wave does both); barriers inside the
+  // two parts are wave-local. Then the helper leaves and one wave carries on.
+  if (tid >= 2 * nthr) return;
+  const bool helper = ngrp > nthr && tid >= nthr;
+  if (helper || ngrp == nthr) {
+    // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
+    const unsigned ln = tid & (SHK_WAVE - 1);
+    {
+      uint64_t ow = 0;
+      if (ln < nown) ow = shk_ld64(oimg + ln * SHK_BLOCK_BYTES + SHK_OFF_OCC);
+      if (ln < SHK_REGION_BLOCKS) oocc[ln] = ow;
+      const uint32_t pc = (uint32_t)__popcll(ow);
+      const uint32_t inc = shk_wave_incl_add(pc);
+      if (ln < SHK_REGION_BLOCKS) oorank[ln] = inc - pc;
+      if (ln == SHK_REGION_BLOCKS - 1) oorank[SHK_REGION_BLOCKS] = inc;
+      uint64_t rw = 0;
+      if (old_any && !fatal && ln < nblk_old) {
+        rw = shk_ld64(oimg + ln * SHK_BLOCK_BYTES + SHK_OFF_RUN);
+        const uint32_t s0 = ln * 64;
+        if (s0 + 64 <= olo || s0 >= ohi) rw = 0;
+        else {
+          if (olo > s0) rw &= ~((1ULL << (olo - s0)) - 1);
+          if (ohi < s0 + 64) rw &= ((1ULL << (ohi - s0)) - 1);
+        }
+      }
+      const uint32_t rc = (uint32_t)__popcll(rw);
+      const uint32_t rinc = shk_wave_incl_add(rc);
+      if (ln < IMG_BLOCKS) { orrank[ln] = rinc - rc; orunw[ln] = rw; }
+      if (ln == SHK_WAVE - 1) orrank[IMG_BLOCKS] = rinc;
+    }
+    shk_wave_sync();
+    const uint32_t nruns = orrank[IMG_BLOCKS];
+    if (nruns != oorank[SHK_REGION_BLOCKS] || nruns > SHK_REGION) {
+      if (ln == 0) { atomicOr(A.err, SHK_E_CORRUPT); atomicOr(&s_fail, SHK_E_CORRUPT); }
+    } else if (!fatal) {
+      // position of the j-th runend: one lane per run (select over the masked runends words)
+      for (uint32_t j = ln; j < nruns; j += SHK_WAVE) {
+        uint32_t lo = 0, hi = IMG_BLOCKS;   // last word w with orrank[w] <= j
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (orrank[mid] <= j) lo = mid; else hi = mid;
+        }
+        orend[j] = (uint16_t)(lo * 64 + shk_select64(orunw[lo], j - orrank[lo]));
+      }
+    }
+    if (helper) { __syncthreads(); return; }   // (the join below)
+    shk_wave_sync();
+  }
   my_added = tid == 0 ? s_added : 0;
   my_added_b = (FUSED && tid == 0) ? s_added_b : 0;
-  SHK_STAMP(1);   // key folding
-
-  // ---- old structure: occupieds of the own blocks, runends inside [olo, ohi)
-  {
-    uint64_t ow = 0;
-    if (tid < nown) ow = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_OCC);
-    if (tid < SHK_REGION_BLOCKS) oocc[tid] = ow;
-    const uint32_t pc = (uint32_t)__popcll(ow);
-    const uint32_t inc = shk_wave_incl_add(pc);
-    if (tid < SHK_REGION_BLOCKS) oorank[tid] = inc - pc;
-    if (tid == SHK_REGION_BLOCKS - 1) oorank[SHK_REGION_BLOCKS] = inc;
-    uint64_t rw = 0;
-    if (old_any && !fatal && tid < nblk_old) {
-      rw = shk_ld64(oimg + tid * SHK_BLOCK_BYTES + SHK_OFF_RUN);
-      const uint32_t s0 = tid * 64;
-      if (s0 + 64 <= olo || s0 >= ohi) rw = 0;
-      else {
-        if (olo > s0) rw &= ~((1ULL << (olo - s0)) - 1);
-        if (ohi < s0 + 64) rw &= ((1ULL << (ohi - s0)) - 1);
-      }
-    }
-    const uint32_t rc = (uint32_t)__popcll(rw);
-    const uint32_t rinc = shk_wave_incl_add(rc);
-    if (tid < IMG_BLOCKS) { orrank[tid] = rinc - rc; orunw[tid] = rw; }
-    if (tid == SHK_WAVE - 1) orrank[IMG_BLOCKS] = rinc;
-  }
-  __syncthreads();
-  const uint32_t nruns_old = orrank[IMG_BLOCKS];
-  if (nruns_old != oorank[SHK_REGION_BLOCKS] || nruns_old > SHK_REGION) {
-    if (tid == 0) atomicOr(A.err, SHK_E_CORRUPT);
-    fatal = true;
-  }
-  // position of the j-th runend: one lane per run (select over the masked runends words)
-  if (!fatal)
-    for (uint32_t j = tid; j < nruns_old; j += nthr) {
-      uint32_t lo = 0, hi = IMG_BLOCKS;   // last word w with orrank[w] <= j
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (orrank[mid] <= j) lo = mid; else hi = mid;
-      }
-      orend[j] = (uint16_t)(lo * 64 + shk_select64(orunw[lo], j - orrank[lo]));
-    }
-
-  SHK_STAMP(2);   // old structure (rank/select)
+  SHK_STAMP(2);   // old structure (rank/select) when this wave did it
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
   const uint32_t nlist = (A.ablate & 16) ? 0 : s_nlist;
   for (uint32_t i = tid; i < nlist; i += nthr) atomicAdd(&qcnt[hkey[slist[i]] >> (SHK_CHUNK_BITS + 8)], 1u);
-  __syncthreads();
+  shk_wave_sync();
   constexpr uint32_t per = SHK_REGION / nthr;  // consecutive quotients per lane
   const uint32_t qa = tid * per;
   {
@@ -440,14 +446,14 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     for (uint32_t j = 0; j < per; j++) { qoff[qa + j] = (uint16_t)ex; ex += qcnt[qa + j]; }
     if (tid == nthr - 1) qoff[SHK_REGION] = (uint16_t)ex;
   }
-  __syncthreads();
+  shk_wave_sync();
   for (uint32_t i = tid; i < nlist; i += nthr) {
     const uint32_t h = slist[i];
     const uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
     const uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
     nidx[pos] = (uint16_t)h;
   }
-  __syncthreads();
+  shk_wave_sync();
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t q = qa + j;
     const uint32_t a = qoff[q], b = qoff[q + 1];
@@ -460,6 +466,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
   }
   // (each lane sorted only its own quotients' segments)
+  __syncthreads();                       // join: the old structure is in place (the helper wave leaves here)
+  if (s_fail & SHK_E_CORRUPT) fatal = true;
 
   SHK_STAMP(3);   // counting sort + per-quotient sort
   // ---- one pass over the quotients: merge old run and new keys -> run length, statistics,

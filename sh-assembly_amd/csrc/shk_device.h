@@ -54,6 +54,12 @@ __device__ __forceinline__ uint64_t shk_ror64(uint64_t v, unsigned s) {
 }
 
 // ---- wave scans (64 lanes, shuffle based)
+// LDS writes of this wave's lanes become visible to its other lanes (a barrier among the 64 lanes only)
+__device__ __forceinline__ void shk_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ uint32_t shk_wave_incl_add(uint32_t x) {
   unsigned lane = shk_lane();
   for (int d = 1; d < SHK_WAVE; d <<= 1) {
