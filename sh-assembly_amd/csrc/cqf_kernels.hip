@@ -220,11 +220,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // IMGB = IMG_BLOCKS normally; the host retries a pass with IMG_BLOCKS_BIG when a cluster is longer.
   constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
   static_assert(IMGB <= SHK_WAVE, "one lane per image block in the rank/select step");
-  __shared__ uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
+  __shared__ __attribute__((aligned(16))) uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
   // occurrences in this batch; FUSED: 64 bits per key, low word = in the chunks <= split, high word = behind it (one LDS atomic)
-  __shared__ __attribute__((aligned(8))) uint32_t hcnt[FUSED ? 2 * SHK_HCAP : SHK_HCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t hcnt[FUSED ? 2 * SHK_HCAP : SHK_HCAP];
   __shared__ uint32_t s_added_b;
-  __shared__ uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
+  __shared__ __attribute__((aligned(16))) uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
   __shared__ uint16_t qoff[SHK_REGION + 2];
   __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
   __shared__ uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
@@ -287,8 +287,13 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     const uint32_t *src = reinterpret_cast<const uint32_t *>(A.tabA + b0 * SHK_BLOCK_BYTES);
     uint32_t *dst = reinterpret_cast<uint32_t *>(oimg);
     if (!(A.ablate & 64)) for (uint32_t i = tid; i < (nbytes + 3) / 4; i += ngrp) dst[i] = src[i];
-    for (uint32_t i = tid; i < SHK_HCAP; i += ngrp) { hkey[i] = SHK_EMPTY; hcnt[i] = 0; if (FUSED) hcnt[SHK_HCAP + i] = 0; }
-    for (uint32_t i = tid; i < SHK_REGION; i += ngrp) qcnt[i] = 0;
+    // (16-byte LDS stores: the LDS pipeline, shared by all waves of the CU, is what this kernel keeps busiest)
+    {
+      const uint4 e4 = make_uint4(SHK_EMPTY, SHK_EMPTY, SHK_EMPTY, SHK_EMPTY), z4 = make_uint4(0, 0, 0, 0);
+      for (uint32_t i = tid; i < SHK_HCAP / 4; i += ngrp) reinterpret_cast<uint4 *>(hkey)[i] = e4;
+      for (uint32_t i = tid; i < (FUSED ? 2 * SHK_HCAP : SHK_HCAP) / 4; i += ngrp) reinterpret_cast<uint4 *>(hcnt)[i] = z4;
+      for (uint32_t i = tid; i < SHK_REGION / 4; i += ngrp) reinterpret_cast<uint4 *>(qcnt)[i] = z4;
+    }
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
@@ -344,12 +349,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           if (!__ballot(pend[u])) continue;   // wave-uniform
-          const uint32_t cur = hkey[h[u]];
-          const bool tryins = pend[u] && cur == SHK_EMPTY;
+          // the CAS both claims an empty slot and tells what the slot holds otherwise (no separate read);
           // 0xFFFFFFFE is never stored (tags use 28 bits, SHK_EMPTY is ~0): that compare cannot succeed
-          const uint32_t prev = atomicCAS(&hkey[h[u]], tryins ? SHK_EMPTY : 0xFFFFFFFEu, want[u] | (SHK_MAX_CHUNKS - 1));
-          const bool ins = tryins && prev == SHK_EMPTY;
-          const uint32_t now = cur != SHK_EMPTY ? cur : (ins ? want[u] : prev);
+          const uint32_t prev = atomicCAS(&hkey[h[u]], pend[u] ? SHK_EMPTY : 0xFFFFFFFEu, want[u] | (SHK_MAX_CHUNKS - 1));
+          const bool ins = pend[u] && prev == SHK_EMPTY;
+          const uint32_t now = ins ? want[u] : prev;
           const bool match = pend[u] && (now >> SHK_CHUNK_BITS) == (want[u] >> SHK_CHUNK_BITS);
           const unsigned long long mi = __ballot(ins);
           if (mi) {   // wave-uniform: first occurrences append their slot to the list
