@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             const unsigned first = (unsigned)(__ffsll((long long)mi) - 1);
             uint32_t base = 0;
             if (lane == first) base = atomicAdd(&s_nlist, (uint32_t)__popcll(mi));
-            base = __shfl(base, first);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);   // (first is wave-uniform: no LDS crossbar)
             if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
           }
           if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
@@ -646,13 +646,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   SHK_STAMP(4);   // merge pass
   if (FUSED) {
     // the intermediate table's (T, c) and run lengths: what the range walk of the round needs to know about this region
-    ShkMPw inc_i = mine_i;
-    for (int d = 1; d < SHK_WAVE; d <<= 1) {
-      ShkMPw y;
-      y.a = __shfl_up(inc_i.a, d);
-      y.b = __shfl_up(inc_i.b, d);
-      if (tid >= (unsigned)d) inc_i = shk_mpw_compose(y, inc_i);
-    }
+    const ShkMPw inc_i = shk_mpw_wave_scan(mine_i);
     reinterpret_cast<uint32_t *>(A.ilens + (size_t)r * SHK_REGION)[tid] = l4i;
     if (__ballot(big_i) && tid == 0) atomicOr(A.err, SHK_E_FUSED);
     if (tid == SHK_WAVE - 1) {
@@ -662,19 +656,16 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
   }
   // wave scan of the free-pointer functions (lane order = quotient order)
-  ShkMPw incl = mine;
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    ShkMPw y;
-    y.a = __shfl_up(incl.a, d);
-    y.b = __shfl_up(incl.b, d);
-    if (tid >= (unsigned)d) incl = shk_mpw_compose(y, incl);
-  }
+  const ShkMPw incl = shk_mpw_wave_scan(mine);
   ShkMP tot, pre;          // (64-bit from here on: the placement works with absolute slots)
-  tot.a = __shfl(incl.a, SHK_WAVE - 1);
-  { const int tb = __shfl(incl.b, SHK_WAVE - 1); tot.b = tb > 0 ? tb : SHK_NEG_INF; }
-  pre.a = __shfl_up(incl.a, 1);
-  { const int pb = __shfl_up(incl.b, 1); pre.b = pb > 0 ? pb : SHK_NEG_INF; }
-  if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
+  tot.a = __builtin_amdgcn_readlane(incl.a, SHK_WAVE - 1);
+  { const int tb = __builtin_amdgcn_readlane(incl.b, SHK_WAVE - 1); tot.b = tb > 0 ? tb : SHK_NEG_INF; }
+  pre.a = 0; pre.b = SHK_NEG_INF;
+  if (MODE == 1 || MODE == 2) {   // (only the placement needs the function in front of every lane)
+    pre.a = __shfl_up(incl.a, 1);
+    { const int pb = __shfl_up(incl.b, 1); pre.b = pb > 0 ? pb : SHK_NEG_INF; }
+    if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
+  }
 
   // per-region statistics (summed later by k_region_scan_c / k_stats_reduce: no same-address atomics)
   if (MODE != 1) {
@@ -719,7 +710,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     }
     reinterpret_cast<uint32_t *>(sp)[tid] = l4;
     const uint32_t sincl = shk_wave_incl_add(st_used);
-    const uint32_t stot = __shfl(sincl, SHK_WAVE - 1);
+    const uint32_t stot = (uint32_t)__builtin_amdgcn_readlane((int)sincl, SHK_WAVE - 1);
     const bool over = !fatal && (__ballot(big) != 0 || stot > SHK_SPILL_PACK_MAX);
     if (tid == 0) {
       A.summary[(size_t)SHK_SUM_STRIDE * r + 6] = over ? 1 : 0;

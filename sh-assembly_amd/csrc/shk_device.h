@@ -60,20 +60,23 @@ __device__ __forceinline__ void shk_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Inclusive scans over the 64 lanes with DPP moves (VALU only: __shfl_up would be a ds_bpermute per step, and the LDS
+// pipeline is what the rebuild kernel keeps busiest): Hillis-Steele inside each row of 16 lanes (row_shr 1,2,4,8), then
+// row_bcast15 / row_bcast31 carry the row totals across rows (GFX9 DPP modes, present on gfx950). A lane without a source
+// (or in a row the step does not touch) receives the operation's identity.
+#define SHK_DPP_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
 __device__ __forceinline__ uint32_t shk_wave_incl_add(uint32_t x) {
-  unsigned lane = shk_lane();
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    uint32_t y = __shfl_up(x, d);
-    if (lane >= (unsigned)d) x += y;
-  }
+#define SHK_STEP_(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xf, true);
+  SHK_DPP_STEPS(SHK_STEP_)
+#undef SHK_STEP_
   return x;
 }
 __device__ __forceinline__ uint64_t shk_wave_incl_add64(uint64_t x) {
-  unsigned lane = shk_lane();
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    uint64_t y = __shfl_up(x, d);
-    if (lane >= (unsigned)d) x += y;
-  }
+#define SHK_STEP_(ctrl, rows) { const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, ctrl, rows, 0xf, true); \
+                              const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), ctrl, rows, 0xf, true); \
+                              x += ((uint64_t)hi_ << 32) | lo_; }
+  SHK_DPP_STEPS(SHK_STEP_)
+#undef SHK_STEP_
   return x;
 }
 // Inclusive XOR scan over the 64 lanes with DPP moves (no LDS crossbar): Hillis-Steele inside
@@ -174,6 +177,16 @@ __device__ __forceinline__ ShkMPw shk_mpw_compose(ShkMPw first, ShkMPw second) {
   r.b = t > second.b ? t : second.b;
   if (r.b < SHK_NEG_INF_W) r.b = SHK_NEG_INF_W;
   return r;
+}
+
+// inclusive scan of f -> max(f + a, b) functions over the 64 lanes in lane order (lane 0's function is applied first)
+__device__ __forceinline__ ShkMPw shk_mpw_wave_scan(ShkMPw x) {
+#define SHK_STEP_(ctrl, rows) { ShkMPw y_; y_.a = __builtin_amdgcn_update_dpp(0, x.a, ctrl, rows, 0xf, true); \
+                              y_.b = __builtin_amdgcn_update_dpp(SHK_NEG_INF_W, x.b, ctrl, rows, 0xf, false); \
+                              x = shk_mpw_compose(y_, x); }
+  SHK_DPP_STEPS(SHK_STEP_)
+#undef SHK_STEP_
+  return x;
 }
 
 // ---- bytes of the packed block image (global or LDS): unaligned little-endian access
