@@ -933,36 +933,31 @@ __global__ void __launch_bounds__(SHK_WAVE) k_region_place(ShkMergeArgs A) {
   const uint8_t *sp = A.spill + (size_t)r * SHK_SPILL_STRIDE;
   const uint32_t l4 = reinterpret_cast<const uint32_t *>(sp)[tid];
   {
-    uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
-    for (uint32_t i = tid; i < (IMG_BYTES + 16) / 4; i += SHK_WAVE) z[i] = 0;
+    uint4 *z = reinterpret_cast<uint4 *>(nimg);          // (16-byte stores; nimg is 16-byte aligned and padded)
+    for (uint32_t i = tid; i < (IMG_BYTES + 16) / 16; i += SHK_WAVE) z[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) for (uint32_t i = ((IMG_BYTES + 16) / 16) * 16; i < IMG_BYTES + 16; i++) nimg[i] = 0;
   }
   constexpr uint32_t per = SHK_REGION / SHK_WAVE;
   const uint32_t qa = tid * per;
-  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  ShkMPw mine; mine.a = 0; mine.b = SHK_NEG_INF_W;       // (region-relative: 32 bits, scanned with DPP moves)
   uint32_t st_used = 0;
 #pragma unroll
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t len = (l4 >> (8 * j)) & 255u;
     if (len) {
-      ShkMP m; m.a = len; m.b = (long long)(qa + j) + len;
-      mine = shk_mp_compose(mine, m);
+      ShkMPw m; m.a = (int)len; m.b = (int)(qa + j + len);
+      mine = shk_mpw_compose(mine, m);
       st_used += len;
     }
   }
-  ShkMP incl = mine;
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    ShkMP y;
-    y.a = __shfl_up(incl.a, d);
-    y.b = __shfl_up(incl.b, d);
-    if (tid >= (unsigned)d) incl = shk_mp_compose(y, incl);
-  }
+  const ShkMPw incl = shk_mpw_wave_scan(mine);
   ShkMP pre;
   pre.a = __shfl_up(incl.a, 1);
-  pre.b = __shfl_up(incl.b, 1);
+  { const int pb = __shfl_up(incl.b, 1); pre.b = pb > 0 ? pb : SHK_NEG_INF; }
   if (tid == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
   const uint32_t sinc = shk_wave_incl_add(st_used);
   const uint32_t ex = sinc - st_used;
-  const uint32_t total = __shfl(sinc, SHK_WAVE - 1);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sinc, SHK_WAVE - 1);
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sp + SHK_SPILL_LENS);
     uint32_t *dst = reinterpret_cast<uint32_t *>(pack);
@@ -1263,24 +1258,20 @@ __device__ __forceinline__ ShkVRegion shk_vregion(const uint64_t *fin, const uin
   R.q0 = r << SHK_REGION_LOG2;
   const uint64_t myq = R.q0 + 4 * lane;
   R.l4 = myq < nslots ? reinterpret_cast<const uint32_t *>(lens + R.q0)[lane] : 0u;   // (regions are whole: nslots is a multiple of 64, lens of absent quotients are 0)
-  ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
+  // (relative to the region's first quotient: 32 bits, scanned with DPP moves -- this kernel is one wave and a chain of
+  // dependent steps, every shuffle through the LDS crossbar is latency on that chain)
+  ShkMPw mine; mine.a = 0; mine.b = SHK_NEG_INF_W;
 #pragma unroll
   for (unsigned j = 0; j < 4; j++) {
     const uint32_t l = (R.l4 >> (8 * j)) & 255u;
-    if (l) { ShkMP m; m.a = l; m.b = (long long)(myq + j) + l; mine = shk_mp_compose(mine, m); }
+    if (l) { ShkMPw m; m.a = (int)l; m.b = (int)(4 * lane + j + l); mine = shk_mpw_compose(mine, m); }
   }
-  ShkMP incl = mine;
-  for (int d = 1; d < SHK_WAVE; d <<= 1) {
-    ShkMP y;
-    y.a = __shfl_up(incl.a, d);
-    y.b = __shfl_up(incl.b, d);
-    if (lane >= (unsigned)d) incl = shk_mp_compose(y, incl);
-  }
+  const ShkMPw incl = shk_mpw_wave_scan(mine);
   ShkMP pre;
   pre.a = __shfl_up(incl.a, 1);
-  pre.b = __shfl_up(incl.b, 1);
+  { const int pb = __shfl_up(incl.b, 1); pre.b = pb > 0 ? pb : SHK_NEG_INF; }
   if (lane == 0) { pre.a = 0; pre.b = SHK_NEG_INF; }
-  R.fpre = (uint64_t)shk_mp_apply(pre, (long long)fin[r]);
+  R.fpre = (uint64_t)(shk_mp_apply(pre, (long long)fin[r] - (long long)R.q0) + (long long)R.q0);
   return R;
 }
 // A filter sharded by quotient range is walked shard by shard (ShkWalkShard): fin is then laid out with the free pointer
