@@ -12,6 +12,8 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="drive the collective flow (shk/dist.py) with one rank over RCCL")
     ap.add_argument("--emu", action="store_true", help="run the kernels in the CPU emulator build (tests/emu/libshk_emu.so; one rank over gloo with --sharded)")
     ap.add_argument("--max-qb", type=int, default=17)
+    ap.add_argument("--qbs", default="", help="comma-separated filter sizes to draw from (default 11..max-qb)")
+    ap.add_argument("--max-reads", type=int, default=4000)
     args = ap.parse_args()
     lib = os.path.join(ROOT, "tests", "emu", "libshk_emu.so") if args.emu else None
     import torch  # noqa: F401  (torch's HIP runtime first)
@@ -27,11 +29,11 @@ def main():
     bad = 0
     t0 = time.time()
     for case in range(args.cases):
-        qb = rnd.choice([q for q in (11, 12, 13, 14, 15, 16, 17) if q <= args.max_qb])
+        qb = rnd.choice([int(x) for x in args.qbs.split(",")] if args.qbs else [q for q in (11, 12, 13, 14, 15, 16, 17) if q <= args.max_qb])
         k = rnd.choice([21, 28, 31, 47, 63, 64, 65, 100])
         L = rnd.choice([max(k + 5, 60), 100, 150])
         cap = int((1 << qb) * 0.45)
-        nreads = max(8, min(4000, cap // max(1, (L - k + 1)) * rnd.choice([1, 2, 3])))
+        nreads = max(8, min(args.max_reads, cap // max(1, (L - k + 1)) * rnd.choice([1, 2, 3])))
         G = max(200, nreads * L // rnd.choice([8, 20, 40]))
         err = rnd.choice([0.0, 0.003, 0.01, 0.03])
         fq = synth.make_fastq(synth.make_genome(G, rnd.randrange(1 << 30)), nreads, L, err, seed=rnd.randrange(1 << 30),
