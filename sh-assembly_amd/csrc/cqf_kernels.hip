@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ __attribute__((aligned(16))) uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
   __shared__ uint16_t qoff[SHK_REGION + 2];
   __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
-  __shared__ uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
+  __shared__ __attribute__((aligned(8))) uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
   __shared__ uint16_t rstart[SHK_REGION];
   __shared__ __attribute__((aligned(16))) uint8_t oimg[IMG_BYTES + 16];
   __shared__ __attribute__((aligned(16))) uint8_t nimg[IMG_BYTES + 16];
@@ -238,6 +238,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ uint32_t orrank[IMG_BLOCKS + 1];
   __shared__ uint32_t lhist[SHK_HIST_BINS];
   __shared__ uint32_t s_fail, s_added, s_nlist;
+  // one private word (pair) per lane: where the branch-free probe loop sends the lanes that have nothing to do, so that
+  // their no-op atomics do not land on random banks next to the real ones (LDS bank conflicts were 18 % of this kernel's
+  // cycles). The words live in `orend`, which is idle until the fold is over -- 512 bytes more would push the plain
+  // kernel's LDS over an allocation step and cost it a workgroup per CU (measured: 12.6 -> 13.7 ms).
+  uint32_t *hidle = reinterpret_cast<uint32_t *>(orend);
 
   unsigned long long t_prev = A.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned tid = threadIdx.x;
@@ -295,6 +300,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       for (uint32_t i = tid; i < SHK_REGION / 4; i += ngrp) reinterpret_cast<uint4 *>(qcnt)[i] = z4;
     }
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
+    if (tid < 2 * SHK_WAVE) hidle[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
       for (uint32_t i = tid; i < (IMG_BYTES + 16) / 4; i += ngrp) z[i] = 0;
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           if (!__ballot(pend[u])) continue;   // wave-uniform
           // the CAS both claims an empty slot and tells what the slot holds otherwise (no separate read);
           // 0xFFFFFFFE is never stored (tags use 28 bits, SHK_EMPTY is ~0): that compare cannot succeed
-          const uint32_t prev = atomicCAS(&hkey[h[u]], pend[u] ? SHK_EMPTY : 0xFFFFFFFEu, want[u] | (SHK_MAX_CHUNKS - 1));
+          const uint32_t prev = atomicCAS(pend[u] ? &hkey[h[u]] : &hidle[lane], pend[u] ? SHK_EMPTY : 0xFFFFFFFEu, want[u] | (SHK_MAX_CHUNKS - 1));
           const bool ins = pend[u] && prev == SHK_EMPTY;
           const uint32_t now = ins ? want[u] : prev;
           const bool match = pend[u] && (now >> SHK_CHUNK_BITS) == (want[u] >> SHK_CHUNK_BITS);
@@ -363,11 +369,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);   // (first is wave-uniform: no LDS crossbar)
             if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
           }
-          if (wh) atomicMin(&hkey[h[u]], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
+          if (wh) atomicMin(match ? &hkey[h[u]] : &hidle[lane], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
           if (FUSED) {
             const unsigned long long inc = match ? (bef[u] ? (unsigned long long)wgt[u] : (unsigned long long)wgt[u] << 32) : 0ULL;
-            atomicAdd(reinterpret_cast<unsigned long long *>(hcnt) + h[u], inc);
-          } else atomicAdd(&hcnt[h[u]], match ? wgt[u] : 0u);
+            atomicAdd(match ? reinterpret_cast<unsigned long long *>(hcnt) + h[u] : reinterpret_cast<unsigned long long *>(hidle) + lane, inc);
+          } else atomicAdd(match ? &hcnt[h[u]] : &hidle[lane], match ? wgt[u] : 0u);
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }
