@@ -16,7 +16,7 @@ from fastq_util import chunks_by_records
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "libshk_emu.so")
 QB, K, TRIG, ND, ML = 11, 28, 650, 2, 1 << 20
-TRIG_ONE_PASS = {2: 420, 4: 880}   # (chosen so that no batch holds two points: every point goes the one-pass way)
+TRIG_ONE_PASS = {2: 420, 4: 880, 8: 1500}   # (chosen so that no batch holds two points: every point goes the one-pass way)
 
 
 def _data(rank, shape=(24, 6)):
@@ -142,11 +142,11 @@ def test_stitched_export_equals_single_table_bytes(tmp_path):
     o.free()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_one_pass_points_make_the_shards_the_single_table(world, tmp_path, monkeypatch):
     """deNoise points taken in one rebuild per shard (shk/dist.py _one_pass_point): the point's chunk guessed from a sample of
     the regions and verified, the round's range walk (short ranges here: many range ends, some next to a shard border)
-    continued from shard to shard over the layout of the single table. Then NOTHING differs from the single filter: rounds,
+    continued from shard to shard over the layout of the single table (with 8 ranks a shard is ONE 256-quotient region). Then NOTHING differs from the single filter: rounds,
     removed counts, counters, and the stitched file is the oracle's .cqf byte for byte"""
     monkeypatch.setenv("SHK_SAMPLE_STRIDE", "2")
     out_path = str(tmp_path / "stitched.cqf")
