@@ -37,6 +37,7 @@ class ShardState:
         self.guesses = 0            # sampled predictions of the point's chunk, and how many the exact histogram confirmed
         self.guesses_right = 0
         self.inexact_rounds = 0     # rounds whose range walk restarted at every shard (only after a flagged one-pass try)
+        self.keep = None
 
 
 def _allreduce(vals, st, op=None):
@@ -236,7 +237,8 @@ def _one_pass_point(ctx, st, lo, split, hi, out, known=False, words=True):
     so, nprot, web = _local(st, lambda: ctx.stage_point_walk(carry[rank], prev_fp[rank], rank == world - 1, nxt_used,
                                                              [int(x) for x in state.tolist()]), ((0, 0), 0, 0xFFFF))
     if rank + 1 < world:
-        dist.send(torch.tensor(list(so), dtype=torch.int64, device=st.device), dst=rank + 1)
+        st.keep = torch.tensor(list(so), dtype=torch.int64, device=st.device)   # (alive until the next point: the send is asynchronous on a GPU)
+        dist.send(st.keep, dst=rank + 1)
     acc = None
     if not web and not st.pending_rc:
         acc = _local(st, lambda: ctx.stage_point_finish(p), None)
