@@ -214,43 +214,53 @@ __device__ __forceinline__ uint32_t shk_segment_end_pre(const unsigned long long
   return len;
 }
 
-// k-mers per read (one wave per read, grid-stride)
+// k-mers per read, one THREAD per read. The wave-per-read form of this kernel (four byte loads, four ballots and the
+// restart loop per read: about 80 wave instructions for 150 bases) was bound by instruction issue, 1.6 ms for 8 M reads;
+// here a thread looks at its read 16 aligned bytes at a time (SWAR compare with 'N'), and only a read that really has an
+// 'N' behind its first window walks the restart rule byte by byte (CQF_mt.h:627-676: the first window of a (sub)read is
+// hashed without being looked at; the read restarts behind the first 'N' at index >= k).
+__device__ __forceinline__ uint32_t shk_bytes_below(uint32_t n) { return n >= 4 ? 0xFFFFFFFFu : ((1u << (8 * n)) - 1u); }
 __global__ void k_count_keys(const uint8_t *text, const uint64_t *rd_start, const uint64_t *rd_end,
                              const uint64_t *nreads_p, uint32_t k, uint32_t *nkeys, uint32_t *err) {
   const uint64_t nreads = *nreads_p;
-  const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / SHK_WAVE);
-  uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / SHK_WAVE) + shk_wave();
-  // two reads ahead for the table entries, one read ahead for the bases: all loads of a read are in
-  // flight while the previous one is counted
-  uint64_t st_n = 0, en_n = 0, st_nn = 0, en_nn = 0;
-  uint32_t c[4], c_n[4];
-  if (r < nreads) { st_n = rd_start[r]; en_n = rd_end[r]; }
-  if (r + nwaves < nreads) { st_nn = rd_start[r + nwaves]; en_nn = rd_end[r + nwaves]; }
-  shk_read_bytes(text, st_n, en_n, shk_lane(), c_n);
-  for (; r < nreads; r += nwaves) {
-    const uint64_t st = st_n, en = en_n;
-#pragma unroll
-    for (int t = 0; t < 4; t++) c[t] = c_n[t];
-    st_n = st_nn; en_n = en_nn;
-    if (r + nwaves < nreads) shk_read_bytes(text, st_n, en_n, shk_lane(), c_n);
-    if (r + 2 * nwaves < nreads) { st_nn = rd_start[r + 2 * nwaves]; en_nn = rd_end[r + 2 * nwaves]; }
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+    const uint64_t st = rd_start[r], en = rd_end[r];
     uint32_t cnt = 0;
-    if (en - st > SHK_MAX_READ) {
-      if (shk_lane() == 0) atomicOr(err, SHK_E_BAD_FASTQ);
-    } else {
+    if (en - st > SHK_MAX_READ) atomicOr(err, SHK_E_BAD_FASTQ);
+    else if (en - st >= k) {
       const uint32_t len = (uint32_t)(en - st);
       const uint8_t *rd = text + st;
-      unsigned long long nm[4];
-      shk_read_masks(c, nm);
-      uint32_t s = 0;
-      while (len >= s + k) {
-        uint32_t e = shk_segment_end_pre(nm, rd, len, s, k);
-        cnt += e - s - k + 1;
-        if (e == len) break;
-        s = e + 1;
+      // is there an 'N' at an index >= k at all?
+      // (offsets into the text buffer, whose base is 16-byte aligned as for k_count_lines: units never start in front of it)
+      const uint64_t a = st + k, e = en;
+      uint32_t any = 0;
+      for (uint64_t u = a & ~15ULL; u < e; u += 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + u);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint64_t b = u + 4 * i;                      // bytes [lo, hi) of this word belong to the inspected part
+          const uint32_t lo = a > b ? (uint32_t)(a - b > 4 ? 4 : a - b) : 0u;
+          const uint32_t hi = e > b ? (uint32_t)(e - b > 4 ? 4 : e - b) : 0u;
+          const uint32_t valid = shk_bytes_below(hi) & ~shk_bytes_below(lo);
+          const uint32_t x = (w[i] ^ 0x4E4E4E4Eu) | ~valid;   // zero byte = an 'N' that counts
+          any |= (x - 0x01010101u) & ~x & 0x80808080u;
+        }
+      }
+      if (!any) cnt = len - k + 1;
+      else {
+        uint32_t s0 = 0;
+        while (len >= s0 + k) {
+          uint32_t e0 = s0 + k;
+          while (e0 < len && rd[e0] != 'N') e0++;
+          cnt += e0 - s0 - k + 1;
+          if (e0 == len) break;
+          s0 = e0 + 1;
+        }
       }
     }
-    if (shk_lane() == 0) nkeys[r] = cnt;
+    nkeys[r] = cnt;
   }
 }
 

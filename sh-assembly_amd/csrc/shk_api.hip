@@ -377,8 +377,9 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   { int rc = parse_stage(c, text, on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads); if (rc) return rc; }
   uint32_t groups = c->hash_groups;
   { uint64_t need = nreads / (c->threads / SHK_WAVE) + 1; if (need < groups) groups = (uint32_t)need; }
-  { ProfScope ps(c, KP_COUNT_KEYS);
-    hipLaunchKernelGGL(k_count_keys, dim3(groups), dim3(c->threads), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
+  { ProfScope ps(c, KP_COUNT_KEYS);       // (one thread per read)
+    const uint64_t blocks = nreads / 256 + 1;
+    hipLaunchKernelGGL(k_count_keys, dim3((uint32_t)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, c->stream, dtext, c->d_rd_start, c->d_rd_end,
                        c->d_scalars + 0, c->cfg.k, c->d_nkeys, c->d_err); }
   if (run_scan<uint32_t>(c, c->d_nkeys, nreads, nullptr, c->d_key_base)) return SHK_ERR_HIP;
   // total = key_base[nreads] -> d_scalars[1]
