@@ -284,8 +284,10 @@ def main():
             self.rounds += st["denoise_rounds"]
             if args.trace and rank == 0:
                 tt = ctx.totals()
-                print("step %d: nelts %d ndistinct %d rounds %d free_pointer %d / %d" % (s, tt.nelts, tt.ndistinct, self.rounds, tt.free_pointer, tt.xnslots),
-                      file=sys.stderr, flush=True)
+                now = time.perf_counter()
+                print("step %d: %.1f ms since the last one; nelts %d ndistinct %d rounds %d free_pointer %d / %d" % (
+                    s, 1e3 * (now - getattr(self, "t_last", now)), tt.nelts, tt.ndistinct, self.rounds, tt.free_pointer, tt.xnslots), file=sys.stderr, flush=True)
+                self.t_last = now
 
     if args.warmup:
         # untimed passes over the first batches into a scratch filter (same geometry, same schedule): loads the code

@@ -172,6 +172,8 @@ template <typename T> static int dmalloc(T **p, uint64_t n) {
 }
 
 // ------------------------------------------------------------------ create / destroy
+static int ensure_chist(shk_ctx *c);
+static int point_alloc(shk_ctx *c);
 extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (!cfg || !out) return SHK_ERR_ARG;
   if (cfg->qb < 6 || cfg->qb > 40 || cfg->hb != cfg->qb + 8 || cfg->k < 1 || cfg->k > SHK_MAX_K) return SHK_ERR_ARG;
@@ -273,6 +275,16 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   HIPCHK(hipMemsetAsync(c->fin[1], 0, ((uint64_t)c->nregions + 2) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->d_err, 0, 16, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  // A context that is going to take deNoise rounds (its own, or as a shard of a filter that does) gets the buffers of the
+  // first-chunk records and of the one-pass point now: allocating gigabytes inside a counting call is a synchronous trip
+  // into the driver in the middle of the build (contexts without rounds never pay for them)
+  if ((cfg->num_denoise > 0 || cfg->num_shards > 1) && c->use_spill && !getenv("SHK_COARSE_HIST")) {
+    if (ensure_chist(c) || point_alloc(c)) { shk_destroy(c); return SHK_ERR_HIP; }
+  }
+  if (cfg->num_shards > 1 && !getenv("SHK_ROUTE_SINGLE_BUFFER")) {     // the two send buffers of shk_route_words, for the same reason
+    for (int b = 0; b < 2; b++)
+      if (dmalloc(&c->d_send[b], c->cfg.max_batch_keys + 1)) { shk_destroy(c); return SHK_ERR_HIP; }
+  }
   *out = c;
   return SHK_OK;
 }
