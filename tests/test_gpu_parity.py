@@ -904,3 +904,31 @@ def test_config5_error_profile_sizing_and_qb33_filter(tmp_path):
     t2 = ctx.totals()
     assert t2.nelts == t.nelts - r1 - r2 and t2.ndistinct == t.ndistinct - r1 - r2 == ctypes_dump_count(ctx)
     ctx.close()
+
+
+# ---------------------------------------------------------------- the driver's bench contract
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """`python bench.py --gpus 1 --steps K --warmup W` as the driver runs it (shorter): stdout is exactly one JSON line with
+    the metric fields, the path-level `roofline` and the `cpu_baseline` of the compiled reference"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "k-mers/s" and d["value"] > 1e9 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 3, 1) and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert abs(d["ms_per_step"] * d["steps"] / 1e3 - d["build_time_s"]) < 1e-6
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["unit"] == "k-mers/s" and cb["cores"] >= 1 and cb["value"] > 1e6 and cb["sample"]
+    # every k-mer of the build was counted: steps x reads x (L - k + 1), minus the reads' N restarts
+    assert d["build_kmers"] > 0.99 * 3 * 8_000_000 * 104
