@@ -358,7 +358,7 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
           words[out + p] = (hv & mask) | chunk_tag;
           if (hist0) {   // the digit exactly as k_rp_scatter computes it (shk_word_region)
             const uint32_t reg = (uint32_t)((((hv & mask) >> 8) - q_lo) >> SHK_REGION_LOG2);
-            atomicAdd(&lh0[(((reg >> dig_shift) & ((1u << dig_bits) - 1)) << ng_log2) | ((uint32_t)((out + p) >> 12) & ((1u << ng_log2) - 1))], 1u);
+            atomicAdd(&lh0[(((reg >> dig_shift) & ((1u << dig_bits) - 1)) << ng_log2) | ((uint32_t)((out + p) >> SHK_RP_TILE0_LOG2) & ((1u << ng_log2) - 1))], 1u);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

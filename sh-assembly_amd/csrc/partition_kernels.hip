@@ -133,7 +133,7 @@ __global__ void k_rp_hist(const uint64_t *words, const uint64_t *n_p, const uint
         const uint64_t i = i0 + (uint64_t)u * blockDim.x + threadIdx.x;
         if (i < hi) {
           const uint32_t dg = (shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
-          const uint32_t grp = (uint32_t)(i / SHK_RP_TILE) & ((1u << lv.ng_log2) - 1);     // the scatter window this key lies in
+          const uint32_t grp = (uint32_t)(i >> SHK_RP_TILE0_LOG2) & ((1u << lv.ng_log2) - 1);     // the (first-level) scatter window this key lies in
           atomicAdd(&lh[(dg << lv.ng_log2) | grp], 1u);
         }
       }
@@ -158,36 +158,42 @@ __global__ void k_rp_group_bases(const uint64_t *sub, uint32_t nd, uint32_t ng_l
 // after the scan the keys are staged digit by digit in LDS and leave as contiguous runs.
 #define SHK_RP_THREADS 512
 #define SHK_RP_KPT (SHK_RP_TILE / SHK_RP_THREADS)
-__global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
-                                                               const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
-                                                               uint64_t *cursor, uint32_t *err) {
+// (TILE_LOG2, THREADS) = (12, 512) for all levels but the first of a context's own partition: (SHK_RP_TILE0_LOG2, 1024)
+template <int TILE_LOG2, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
+                                                        const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
+                                                        uint64_t *cursor, uint32_t *err) {
+  constexpr uint32_t SHK_RP_TILE_ = 1u << TILE_LOG2;
+  constexpr int KPT_ = (int)(SHK_RP_TILE_ / THREADS);   // keys per thread (registers)
+  static_assert(SHK_RP_TILE_ <= 65536, "a rank inside a digit takes 16 bits");
   __shared__ uint32_t lh[SHK_RP_MAXP];      // digit counts (= next rank while counting)
   __shared__ uint32_t lbase[SHK_RP_MAXP];   // local exclusive base of each digit
   __shared__ uint64_t gbase[SHK_RP_MAXP];   // reserved global base of each digit
-  __shared__ uint64_t stage[SHK_RP_TILE];
+  __shared__ uint64_t stage[SHK_RP_TILE_];
   __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
   const uint64_t n = *n_p;
-  const uint64_t wstart = (uint64_t)blockIdx.x * SHK_RP_TILE;
+  const uint64_t wstart = (uint64_t)blockIdx.x * SHK_RP_TILE_;
   if (wstart >= n) return;
-  const uint64_t wend = wstart + SHK_RP_TILE < n ? wstart + SHK_RP_TILE : n;
+  const uint64_t wend = wstart + SHK_RP_TILE_ < n ? wstart + SHK_RP_TILE_ : n;
   const uint32_t P = 1u << lv.bits;
-  for (uint32_t b = tfb[blockIdx.x]; b < lv.nbuckets && bucket_base[b] < wend; b++) {
+  // (tfb is indexed by 4096-key windows)
+  for (uint32_t b = (lv.nbuckets > 1 ? tfb[(uint64_t)blockIdx.x << (TILE_LOG2 - 12)] : 0u); b < lv.nbuckets && bucket_base[b] < wend; b++) {
     const uint64_t lo = bucket_base[b] > wstart ? bucket_base[b] : wstart;
     const uint64_t hi = bucket_base[b + 1] < wend ? bucket_base[b + 1] : wend;
     if (hi <= lo) continue;
     const uint32_t cnt = (uint32_t)(hi - lo);
-    for (uint32_t d = threadIdx.x; d < P; d += SHK_RP_THREADS) lh[d] = 0;
-    uint64_t w[SHK_RP_KPT];
+    for (uint32_t d = threadIdx.x; d < P; d += THREADS) lh[d] = 0;
+    uint64_t w[KPT_];
 #pragma unroll
-    for (int u = 0; u < SHK_RP_KPT; u++) {
-      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+    for (int u = 0; u < KPT_; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * THREADS;
       w[u] = i < cnt ? in[lo + i] : 0;
     }
     __syncthreads();
-    uint32_t dr[SHK_RP_KPT];               // digit << 16 | rank inside the digit (rank < SHK_RP_TILE)
+    uint32_t dr[KPT_];               // digit << 16 | rank inside the digit (rank < SHK_RP_TILE)
 #pragma unroll
-    for (int u = 0; u < SHK_RP_KPT; u++) {
-      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+    for (int u = 0; u < KPT_; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * THREADS;
       dr[u] = 0;
       if (i < cnt) {
         const uint32_t d = (shk_word_region(w[u], lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *i
     __syncthreads();
     // exclusive scan of the digit counts (P <= 1024)
     uint32_t carry = 0;
-    for (uint32_t d0 = 0; d0 < P; d0 += SHK_RP_THREADS) {
+    for (uint32_t d0 = 0; d0 < P; d0 += THREADS) {
       uint32_t d = d0 + threadIdx.x;
       uint32_t v = d < P ? lh[d] : 0, tot;
       uint32_t ex = shk_block_exscan(v, &tot, scratch);
@@ -210,12 +216,12 @@ __global__ void __launch_bounds__(SHK_RP_THREADS) k_rp_scatter(const uint64_t *i
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < SHK_RP_KPT; u++) {
-      const uint32_t i = threadIdx.x + (uint32_t)u * SHK_RP_THREADS;
+    for (int u = 0; u < KPT_; u++) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * THREADS;
       if (i < cnt) stage[lbase[dr[u] >> 16] + (dr[u] & 0xFFFFu)] = w[u];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt; i += SHK_RP_THREADS) {
+    for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) {
       uint64_t x = stage[i];
       uint32_t d = (shk_word_region(x, lv.hb, lv.q_lo) >> lv.shift) & (P - 1);
       if (lv.out32) {

@@ -437,8 +437,12 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
     { ProfScope ps(c, KP_RP_SCATTER);
       ShkRpLevel lvl = c->lv[l];
       if (const char *e = getenv("SHK_RP_ABLATE")) lvl.ablate = (uint32_t)atoi(e);
-      hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
-                         c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err); }
+      if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
+        hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
+                           c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err);
+      else
+        hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
+                           c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err); }
     cur ^= 1;
     in = c->d_words[cur];
   }
@@ -1287,7 +1291,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   HIPCHK(hipMemcpyAsync(cursor, bb.data(), nshards * 8, hipMemcpyHostToDevice, c->stream));
   (void)base;
   { ProfScope ps(c, KP_RP_SCATTER);
-    hipLaunchKernelGGL(k_rp_scatter, dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], send, n_p,
+    hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, c->d_words[0], send, n_p,
                        c->d_base[0], c->d_tfb, lv, cursor, c->d_err); }
   HIPCHK(hipGetLastError());
   *d_out = send;

@@ -53,6 +53,13 @@ __device__ __forceinline__ uint64_t shk_ror64(uint64_t v, unsigned s) {
   return s ? (v >> s) | (v << (64 - s)) : v;
 }
 
+// keys per window of the FIRST partition level: 16384 = what one workgroup can stage in LDS. Its 128 output streams lie
+// pages apart and three of four digit-run stores of a 4096-key window missed the first-level TLB (19.5 M misses per
+// launch against 30 k in the later levels, whose streams stay inside one bucket): longer runs = fewer misses per key.
+// Measured on 832 M keys: 4.7 ms (4096) -> 3.6 (8192) -> 2.7 ms (16384). The later levels keep 4096-key windows
+// (SHK_RP_TILE): 8192 made them slower.
+#define SHK_RP_TILE0_LOG2 14
+
 // ---- wave scans (64 lanes, shuffle based)
 // LDS writes of this wave's lanes become visible to its other lanes (a barrier among the 64 lanes only)
 __device__ __forceinline__ void shk_wave_sync() {
