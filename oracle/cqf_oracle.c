@@ -86,22 +86,9 @@ static inline uint64_t bitselect(uint64_t v, int rank) {
 }
 static inline uint64_t bitselectv(uint64_t v, int ignore, int rank) { return bitselect(v & ~BITMASK(ignore % 64), rank); }
 
-static uint64_t run_end(const orc_qf *qf, uint64_t q);
-
-/* gqf.c:580-591 */
-static uint64_t block_offset(const orc_qf *qf, uint64_t b) {
-  if (OFF(qf, b) < 255) return OFF(qf, b);
-  return run_end(qf, 64 * b - 1) - 64 * b + 1;
-}
-/* gqf.c:599-601 */
-static uint64_t block_offset_strict(const orc_qf *qf, uint64_t b) {
-  return run_end(qf, 64 * b - 1) - 64 * b + 1;
-}
-
-/* gqf.c:655-704 */
-static uint64_t run_end(const orc_qf *qf, uint64_t q) {
+/* gqf.c:655-704 with the block's offset handed in */
+static uint64_t run_end_at(const orc_qf *qf, uint64_t q, uint64_t boff) {
   uint64_t bi = q / 64, off = q % 64;
-  uint64_t boff = block_offset(qf, bi);
   uint64_t rank = bitrank(occw(qf, bi), off);
   if (rank == 0) {
     if (boff <= off) return q;
@@ -123,6 +110,26 @@ static uint64_t run_end(const orc_qf *qf, uint64_t q) {
   uint64_t ri = 64 * rb + ro;
   return ri < q ? q : ri;
 }
+
+/* gqf.c:599-601: run_end(64 b - 1) - 64 b + 1. The reference evaluates the saturated case (stored offset 255) by
+ * mutual recursion block_offset <-> run_end, one level per saturated block in front of b; on an over-full table that
+ * chain is the whole table and the recursion overruns the stack (round-2 fuzz, qb 24). Same function, as a loop: go
+ * back to the nearest block whose stored offset is exact (block 0's always is), then forward. */
+static uint64_t block_offset_strict(const orc_qf *qf, uint64_t b) {
+  if (b == 0) return 0; /* never asked for: block 0's offset is 0 by construction */
+  uint64_t b0 = b - 1;
+  while (b0 > 0 && OFF(qf, b0) >= 255) b0--;
+  uint64_t off = b0 == 0 ? (OFF(qf, 0) < 255 ? OFF(qf, 0) : 0) : OFF(qf, b0);
+  for (uint64_t bi = b0 + 1; bi <= b; bi++) off = run_end_at(qf, 64 * bi - 1, off) - 64 * bi + 1;
+  return off;
+}
+/* gqf.c:580-591 */
+static uint64_t block_offset(const orc_qf *qf, uint64_t b) {
+  if (OFF(qf, b) < 255) return OFF(qf, b);
+  return block_offset_strict(qf, b);
+}
+/* gqf.c:655-704 */
+static uint64_t run_end(const orc_qf *qf, uint64_t q) { return run_end_at(qf, q, block_offset(qf, q / 64)); }
 
 /* gqf.c:706-718 */
 static int offset_lower_bound(const orc_qf *qf, uint64_t slot) {
@@ -272,6 +279,10 @@ orc_qf *orc_qf_load(const char *path) {
 static void insert_one_slot(orc_qf *qf, uint64_t q, uint64_t pos, uint64_t value) {
   uint64_t e = orc_find_first_empty_slot(qf, pos);
   if (e >= qf->xnslots) { qf->full = 1; return; } /* the reference runs off the end here (undetected) */
+  /* a shift over more than 2^20 slots: one cluster 64 times the CLUSTER_SIZE = 2^14 the reference's region locks assume
+   * (gqf.c:53, 174-199) -- the table is over-full for every purpose and each further insert would move megabytes;
+   * treated like the overrun (full is sticky, the tests discard such a table) */
+  if (e - pos > (1ULL << 20)) { qf->full = 1; return; }
   for (uint64_t i = e; i > pos; i--) {
     set_slot(qf, i, get_slot(qf, i - 1));
     set_runend(qf, i, is_runend(qf, i - 1));

@@ -51,12 +51,28 @@ struct RefQF {
   uint64_t ndistinct;  // runtime->ndistinct  (CQF_mt.h:277)
 };
 
+// The reference's slot accessors load and store 8 bytes at a slot's address whatever the slot width (gqf.c:542-574), so
+// with the last slots of the overflow tail in use they touch up to 7 bytes behind the calloc(size) of qf_init /
+// qf_deserialize (gqf.c:2236, 2416) -- a heap overrun in the reference itself (tests/test_oracle.py shows it under
+// AddressSanitizer). The checker must survive any scenario, so the driver re-allocates the table with two zeroed guard
+// blocks behind it; metadata->size and everything the reference reads or writes inside the table are unchanged.
+// REF_NO_GUARD=1 keeps the reference's own allocation (used by that test only).
+static void guard_table(QF *qf) {
+  if (getenv("REF_NO_GUARD")) return;
+  uint64_t size = qf->metadata->size;
+  void *p = realloc((void *)qf->blocks, size + 2 * 89 + 16);
+  if (!p) abort();
+  memset((char *)p + size, 0, 2 * 89 + 16);
+  qf->blocks = (qfblock *)p;
+}
+
 RefQF *ref_qf_new(uint64_t qb, uint64_t hb, uint32_t seed) {
   RefQF *h = new RefQF();
   // CQF_mt ctor, cqf/CQF_mt.h:427-445
   uint64_t nslots = 1ULL << qb;
   if (qb == hb) qf_init(&h->qf, nslots, hb + 8, 0, true, "", seed);
   else          qf_init(&h->qf, nslots, hb, 0, true, "", seed);
+  guard_table(&h->qf);
   h->nelts = h->ndistinct = 0;
   return h;
 }
@@ -152,6 +168,7 @@ void ref_qf_serialize(RefQF *h, const char *path) {
 RefQF *ref_qf_load(const char *path) {
   RefQF *h = new RefQF();
   qf_deserialize(&h->qf, path);
+  guard_table(&h->qf);
   h->nelts = h->qf.metadata->nelts;
   h->ndistinct = h->qf.metadata->ndistinct_elts;
   return h;

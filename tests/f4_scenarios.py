@@ -54,12 +54,13 @@ def slots_needed(kc):
 
 
 def fits(qb, kc):
-    """keep the scenarios away from a full table: the reference has no capacity check and its 8-byte slot accesses
-    run past its buffer when the last slots of the overflow tail are in use (heap corruption in the checker)"""
+    """keep the scenarios inside the table: the reference has no capacity check (it runs off the end of a full table).
+    Its 8-byte slot accesses behind the last slots of the overflow tail are covered by the guard blocks the driver gives
+    every reference table (oracle/ref_driver.cpp: guard_table; tests/test_oracle.py shows the overrun under ASan)."""
     merged = {}
     for k, c in kc:
         merged[k] = merged.get(k, 0) + c
-    assert slots_needed(merged.items()) <= 0.85 * (1 << qb), "scenario too full for the reference to survive"
+    assert slots_needed(merged.items()) <= 0.95 * (1 << qb), "scenario too full"
 
 
 def checker():

@@ -1,5 +1,6 @@
 """GPU parity tests (-m gpu): the HIP path through the C ABI (libshk.so) against the oracle
 on the same seeded inputs. Bit-exact: table bytes, 128-byte header, counters."""
+import ctypes as C
 import os
 
 import pytest
@@ -524,6 +525,15 @@ def test_contiger_at_celegans_table_size(tmp_path):
     ctx.close()
 
 
+def _sha256_file(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def test_full_size_schedule_independent_of_batching(tmp_path):
     """BASELINE size (C. elegans sizing: qb 29, one bench batch of 8 M reads = 832 M k-mers) with deNoise points inside
     the batch: table, counters, rounds and removed counts do not depend on how the 302 chunks are split into calls (the
@@ -565,9 +575,30 @@ def test_full_size_schedule_independent_of_batching(tmp_path):
             assert o.L.orc_qf_dump(o.h, None, None, 0) == t.ndistinct      # entries found by the CPU decode
             assert (o.nelts(), o.ndistinct()) == (t.nelts, t.ndistinct)    # header counters
             o.free()
+            file_sha = _sha256_file(p)
             os.remove(p)
         ctx.close()
     assert results[0] == results[1]
+    # BYTE FOR BYTE at this size: the same 302 chunks through the t = 1 schedule on the CPU checker -- the compiled reference
+    # (oracle/_ref: the real gqf.c + nthash.hpp; ~2 min at ~7 M k-mers/s) when its library travelled, else the C restatement
+    lib = cqflibs.ref() if cqflibs.have_ref() else cqflibs.oracle()
+    host = text.cpu().numpy()
+    del text, genome
+    q = lib.new(qb)
+    left, trigger, rounds, removed = 2, 60_000_000, 0, 0
+    for a, n in zip(offs, lens):
+        getattr(lib.L, lib.p + "reads_to_kmers")(q.h, C.cast(host.ctypes.data + a, C.c_char_p), n, K)
+        if left and q.ndistinct() >= trigger:                      # CQF_mt.h:837
+            left -= 1
+            removed += q.denoise_round()
+            rounds += 1
+    assert (rounds, removed, q.nelts(), q.ndistinct()) == (results[0][3], results[0][4], results[0][1], results[0][2])
+    assert hashlib.sha256(q.blocks()).hexdigest() == results[0][0], "qb-29 table bytes differ from the CPU reference"
+    p = str(tmp_path / "cpu.cqf")
+    q.serialize(p)                                                 # header (qfmetadata) + blocks as the reference writes them
+    q.free()
+    assert _sha256_file(p) == file_sha, ".cqf file differs from the CPU reference's"
+    os.remove(p)
 
 
 def test_region_hash_overflow_halves_the_chunk_range():

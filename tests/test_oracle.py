@@ -14,6 +14,7 @@ import random
 import pytest
 
 import cqflibs
+import synth
 from cqf_canon import build_blocks, denoise_survivors
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -216,6 +217,69 @@ def test_oracle_vs_reference_saturated_offsets():
         assert o.blocks() == r.blocks() == build_blocks(qb, qb + 8, denoise_survivors(qb, tot))
         o.free(), r.free()
     assert done >= 4
+
+
+@needs_ref
+def test_oracle_vs_reference_high_load_with_long_saturated_chains():
+    """99 % of the slots in use (beyond the 95 % the bench runs the filter to): clusters of thousands of slots, chains of dozens of
+    blocks whose stored offset is saturated at 255 -- the oracle evaluates those by a loop where the reference recurses
+    (gqf.c:580-591 <-> :655-704); inserts through reads_to_kmers, then a deNoise round, then lookups"""
+    R = cqflibs.ref()
+    qb, k = 18, 63
+    g = synth.make_genome(60000, 17)
+    fq = synth.make_fastq(g, 5650, 110, 0.02, seed=5)      # ~270 k k-mers, most of them distinct
+    o, r = O.new(qb), R.new(qb)
+    o.reads_to_kmers(fq, k), r.reads_to_kmers(fq, k)
+    assert not o.full()
+    blocks = o.blocks()
+    assert blocks == r.blocks() and (o.nelts(), o.ndistinct()) == (r.nelts(), r.ndistinct())
+    from f4_scenarios import slots_needed
+    assert slots_needed(o.dump()) > 0.98 * (1 << qb)
+    offs = [blocks[b * 89] for b in range(len(blocks) // 89)]
+    run, best = 0, 0
+    for x in offs:
+        run = run + 1 if x == 255 else 0
+        best = max(best, run)
+    assert best >= 12                                           # chains of saturated blocks
+    assert o.check_offset() and r.check_offset()
+    rnd = random.Random(1)
+    for key, c in rnd.sample(o.dump(), 300):
+        assert o.count(key) == r.count(key) == c
+    assert o.denoise_round(1 << 12) == r.denoise_round(1 << 12)
+    assert o.blocks() == r.blocks()
+    o.free(), r.free()
+
+
+def test_oracle_survives_an_overfull_table():
+    """round 2's fuzz crash: more distinct keys than slots -> one cluster over the whole table, every block's offset
+    saturated; the reference's block_offset/run_end recursion (one level per saturated block) overran the stack in the
+    restatement too. Now a loop; the oracle reports `full` (sticky) and stays inside its allocation."""
+    qb, k = 22, 100
+    fq = synth.make_fastq(synth.make_genome(600000, 5), 110000, 150, 0.03, seed=7)   # 5.6 M k-mers, nearly all distinct
+    o = O.new(qb)
+    o.reads_to_kmers(fq, k)
+    assert o.full() and o.ndistinct() > 0.98 * (1 << qb)
+    o.free()
+
+
+@needs_ref
+def test_reference_slot_access_overruns_its_allocation_without_the_guard():
+    """the reference's gqf.c under AddressSanitizer (oracle/Makefile `asan`, oracle/asan_probe.cpp): with the last slots
+    of the overflow tail in use its 8-byte slot accesses (gqf.c:542-574) pass the calloc of qf_init. ref_driver.cpp
+    therefore gives every reference table guard blocks: with them the same scenario is clean, so test scenarios
+    may fill the tail without corrupting the checker's heap."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/root/reference/cqf/gqf.c"):
+        pytest.skip("needs the reference sources to build the ASan probe")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    probe = os.path.join(root, "oracle", "_ref", "asan_probe")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")       # qf_destroy leaks the lock array (gqf.c:2306-2317)
+    env.pop("LD_PRELOAD", None)
+    ok = subprocess.run([probe], env=env, capture_output=True, text=True)
+    assert ok.returncode == 0 and "probe ok" in ok.stdout, ok.stderr[-2000:]
+    bad = subprocess.run([probe], env=dict(env, REF_NO_GUARD="1"), capture_output=True, text=True)
+    assert bad.returncode != 0 and "heap-buffer-overflow" in bad.stderr and "gqf.c" in bad.stderr
 
 
 def test_contiger_roll_sequence_equals_scratch_hashes():

@@ -36,6 +36,10 @@ def main():
         nreads = max(8, min(args.max_reads, cap // max(1, (L - k + 1)) * rnd.choice([1, 2, 3])))
         G = max(200, nreads * L // rnd.choice([8, 20, 40]))
         err = rnd.choice([0.0, 0.003, 0.01, 0.03])
+        # keep most big cases inside the table: expected slots ~ genome k-mers (with their counters) + one per erroneous
+        # k-mer occurrence; an over-full draw costs the oracle tens of seconds before it reports `full` and is skipped
+        while nreads > 64 and 1.3 * min(G, nreads * (L - k + 1)) + nreads * (L - k + 1) * (1 - (1 - err) ** k) > 0.9 * (1 << qb):
+            nreads = nreads * 3 // 4
         fq = synth.make_fastq(synth.make_genome(G, rnd.randrange(1 << 30)), nreads, L, err, seed=rnd.randrange(1 << 30),
                               n_frac=rnd.choice([0.0, 0.02, 0.2]), short_frac=rnd.choice([0.0, 0.05]), lower_frac=rnd.choice([0.0, 0.05]))
         per = max(1, nreads // rnd.choice([1, 3, 7, 20]))
