@@ -383,7 +383,10 @@ __global__ void __launch_bounds__(SHK_WAVE) k_ug_walk(ShkUG G, const uint32_t *a
     if (turn) {
       const shk_u128 nfirst = rcw, ncur = shk_ug_rc(first, k), nrc = first;
       first = nfirst; win = ncur; rcw = nrc;
-      kind |= 2u | 4u;
+      // the seed k-mer itself need not be solid for extensions (its count is tested against -x/-X, the walk's
+      // neighbours against -s): k_ug_emit, which follows solid successors, is told the one base it cannot find that way --
+      // the last base of RC(seed), appended at position l1 - 1 of the final orientation (bit 3 + bits 4-5 of kind)
+      kind = (uint8_t)((kind & 0x07u) | 2u | 4u | 8u | ((3u - ((unsigned)(nrc >> (2 * (k - 1))) & 3u)) << 4));
       if (sub == 0) { G.first_lo[id] = (uint64_t)first; G.first_hi[id] = (uint64_t)(first >> 64); G.l1[id] = len; }
       continue;                                                // second call, same lanes, remaining step budget
     }
@@ -420,10 +423,11 @@ __global__ void k_ug_emit(ShkUG G, uint32_t n, const uint32_t *keep, const uint6
   const uint64_t kmask = hb >= 64 ? ~0ULL : ((1ULL << hb) - 1);
   const shk_u128 wmask = shk_ug_mask(k);
   shk_u128 win = ((shk_u128)G.first_hi[id] << 64) | G.first_lo[id];
-  const uint32_t len = G.len[id];
+  const uint32_t len = G.len[id], l1 = G.l1[id];
+  const uint8_t kind = G.kind[id];
   const uint64_t o = off[id];
   const uint64_t u = newid[id];                  // 0-based final number
-  out_off[u] = o; out_len[u] = len; out_l1[u] = G.l1[id];
+  out_off[u] = o; out_len[u] = len; out_l1[u] = l1;
   for (uint32_t j = 0; j < k; j++) bases[o + j] = "ACGT"[(unsigned)(win >> (2 * (k - 1 - j))) & 3u];
   uint64_t fh, rh;
   shk_ug_hash(win, k, &fh, &rh);
@@ -438,11 +442,19 @@ __global__ void k_ug_emit(ShkUG G, uint32_t n, const uint32_t *keep, const uint6
     const uint64_t rbase = shk_ror64(rh ^ shk_code_seed_rc(s0), 1);
     unsigned xc = 0;
     uint64_t cx = 0, fx = 0, rx = 0;
-    for (unsigned x = 0; x < 4; x++) {
-      const uint64_t f = fbase ^ shk_code_seed(x);
-      const uint64_t r = rbase ^ shk_rol64(shk_code_seed_rc(x), (k - 1) & 63);
-      const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, 2, &trav);
-      if (cnt >= amin) { xc = x; cx = cnt; fx = f; rx = r; }
+    if ((kind & 8u) && p == l1 - 1) {
+      // the step onto RC(seed k-mer): taken whatever its count (see k_ug_walk's turn)
+      xc = (kind >> 4) & 3u;
+      fx = fbase ^ shk_code_seed(xc);
+      rx = rbase ^ shk_rol64(shk_code_seed_rc(xc), (k - 1) & 63);
+      cx = shk_lookup_one(tab, (fx < rx ? fx : rx) & kmask, q_lo, nslots, 2, &trav);
+    } else {
+      for (unsigned x = 0; x < 4; x++) {
+        const uint64_t f = fbase ^ shk_code_seed(x);
+        const uint64_t r = rbase ^ shk_rol64(shk_code_seed_rc(x), (k - 1) & 63);
+        const uint64_t cnt = shk_lookup_one(tab, (f < r ? f : r) & kmask, q_lo, nslots, 2, &trav);
+        if (cnt >= amin) { xc = x; cx = cnt; fx = f; rx = r; }
+      }
     }
     bases[o + p] = "ACGT"[xc];
     counts[o + p - k + 1] = cx > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cx;

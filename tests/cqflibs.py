@@ -80,6 +80,21 @@ class _QF:
         assert rc == 0
         return out.raw[:ln.value], md.value, (st[0], st[1])
 
+    def contiger(self, text: bytes, offs, lens, k, abundance_min=2, solid_min=2, solid_max=1000000, rule=1, drain_per_read=True):
+        """the whole of Contiger as one sequential program (oracle/contiger_pipeline.cpp; oracle only): returns
+        (text of unitigs.fa, stats). Sets the filter's traveled bits like the reference does. rule: 0 = every chunk by the
+        master's loop (seed at len/2), 1 = by processDataChunk (len/2 - K/2), 2 = alternating"""
+        n = len(offs)
+        o = (C.c_uint64 * max(n, 1))(*offs)
+        ln = (C.c_uint64 * max(n, 1))(*lens)
+        out_len = C.c_uint64()
+        st = (C.c_uint64 * 6)()
+        p = self.L.orc_contiger_run(self.h, text, o, ln, n, k, abundance_min, solid_min, solid_max,
+                                    (rule << 1) | (0 if drain_per_read else 1), C.byref(out_len), st)
+        fa = C.string_at(p, out_len.value)
+        self.L.orc_contiger_free(p)
+        return fa, dict(zip(("seeds", "queued", "cleared", "lookups", "contigs", "map_entries"), list(st)))
+
     def extend_forward(self, seq: bytes, median, k, abundance_min, max_len):
         """(sequence, median, stop, branch mask, neighbour counts[8]): one get_unitig_forward (oracle only)"""
         buf = C.create_string_buffer(seq, max_len + 1)
@@ -168,6 +183,10 @@ class _Lib:
                                         C.POINTER(u32)])
             sig("unitig_from_seed", i32, [vp, C.c_char_p, u32, C.c_uint, u64, u32, C.c_char_p, C.POINTER(u32),
                                           C.POINTER(i32), C.POINTER(C.c_uint8)])
+            L.orc_contiger_run.restype = C.c_void_p
+            L.orc_contiger_run.argtypes = [vp, C.c_char_p, C.POINTER(u64), C.POINTER(u64), u32, C.c_uint, u64, u64, u64, u32,
+                                           C.POINTER(u64), C.POINTER(u64)]
+            L.orc_contiger_free.argtypes = [vp]
         if p == "ref_":
             sig("encode_counter", i32, [vp, u64, u64, C.POINTER(u64)])
             if hasattr(L, "ref_qf_merge"):
