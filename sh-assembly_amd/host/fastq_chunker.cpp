@@ -16,6 +16,7 @@ class PlainSource : public ByteSource {
   ~PlainSource() override { fclose(f_); }
   uint64_t read(char *dst, uint64_t n) override { return fread(dst, 1, n, f_); }
   bool at_end() const override { return feof(f_) != 0; }
+  bool failed() const override { return ferror(f_) != 0; }
 
  private:
   FILE *f_;
@@ -27,12 +28,20 @@ class GzipSource : public ByteSource {
   ~GzipSource() override { gzclose(g_); }
   uint64_t read(char *dst, uint64_t n) override {
     const int r = gzread(g_, dst, (unsigned)n);
-    return r > 0 ? (uint64_t)r : 0;
+    if (r < 0) { failed_ = true; return 0; }          // corrupt or truncated stream (Z_DATA_ERROR, Z_BUF_ERROR)
+    if ((uint64_t)r < n) {                            // a short read: the clean end of the stream, or its premature end
+      int e = Z_OK;
+      gzerror(g_, &e);
+      if (e != Z_OK && e != Z_STREAM_END) failed_ = true;
+    }
+    return (uint64_t)r;
   }
   bool at_end() const override { return gzeof(g_) != 0; }
+  bool failed() const override { return failed_; }
 
  private:
   gzFile g_;
+  bool failed_ = false;
 };
 
 // libbz2's stream-reading interface (bzlib.h: BZ2_bzReadOpen / BZ2_bzRead / BZ2_bzReadClose), bound with dlopen: the
@@ -71,6 +80,7 @@ class Bzip2Source : public ByteSource {
     return r > 0 ? (uint64_t)r : 0;
   }
   bool at_end() const override { return err_ == 4; }   // BZ_STREAM_END (cqf/CQF_mt.h:567)
+  bool failed() const override { return err_ < 0; }    // BZ_DATA_ERROR, BZ_UNEXPECTED_EOF, ...
 
  private:
   FILE *f_;
@@ -125,6 +135,7 @@ uint64_t fastq_record_cut(const char *text, uint64_t n, uint32_t overhead) {
   // decide about them (candidate k needs the starts of lines k+1, k+2 and k+3)
   int64_t ls[9];
   int64_t from = v.n - overhead / 2;
+  if (from < 0) from = 0;                  // a buffer shorter than the probe distance is scanned from its start
   for (int j = 0; j < 9; j++) {
     ls[j] = v.line_start_after(from);
     if (ls[j] < 0) return 0;
@@ -145,6 +156,11 @@ uint64_t fastq_record_cut(const char *text, uint64_t n, uint32_t overhead) {
 seqFile_batch::seqFile_batch(const std::vector<std::string> &file_names, FILE_TYPE, FILE_MODE fm, uint64_t part_size,
                              uint32_t overhead)
     : part_size_(part_size), overhead_(overhead) {
+  if (part_size_ < overhead_) {            // the cut is searched in the last overhead/2 bytes OF A PART (CQF_mt.h:742-743, 781)
+    fprintf(stderr, "Error: part size %llu below the chunker's overhead %u\n", (unsigned long long)part_size_, overhead_);
+    bad_ = true;
+    return;
+  }
   for (const auto &name : file_names) {   // getFileReader, cqf/CQF_mt.h:933-957: unreadable files are skipped
     std::unique_ptr<OpenFile> f(new OpenFile());
     f->src = ByteSource::open(name, fm);
@@ -170,7 +186,16 @@ bool seqFile_batch::next_part(OpenFile &f, chunk &out) {
   char *buf = (char *)malloc(carried + part_size_ + 1);
   if (!buf) { bad_ = true; return false; }
   if (carried) memcpy(buf, f.carry.data(), carried);
-  const uint64_t total = carried + f.src->read(buf + carried, part_size_);
+  const uint64_t got = f.src->read(buf + carried, part_size_);
+  if (f.src->failed() || (got == 0 && !f.src->at_end())) {
+    // a decompressor error (corrupt or truncated .gz / .bz2) or a read that makes no progress: an I/O error, not an
+    // empty part -- the reference would loop on it or run over its buffer (CQF_mt.h:749-760 take gzread's -1 as a size)
+    fprintf(stderr, "Error: cannot read on in an input file (corrupt or truncated?)\n");
+    free(buf);
+    bad_ = true;
+    return false;
+  }
+  const uint64_t total = carried + got;
   if (f.src->at_end()) {
     out.set(buf, total);
     return true;

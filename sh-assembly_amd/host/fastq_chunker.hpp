@@ -30,6 +30,7 @@ class ByteSource {
   virtual ~ByteSource() {}
   virtual uint64_t read(char *dst, uint64_t n) = 0;   // bytes delivered (short only at the end of the stream)
   virtual bool at_end() const = 0;                    // the format's own end-of-stream flag (raised by a short read)
+  virtual bool failed() const = 0;                    // the stream is damaged (decompressor / read error): no further data
   static std::unique_ptr<ByteSource> open(const std::string &path, FILE_MODE mode);   // null when unreadable
 };
 

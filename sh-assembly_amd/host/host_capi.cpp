@@ -20,6 +20,17 @@ uint64_t shkh_chunk_sizes(const char **paths, int nfiles, int mode, uint64_t par
   while (b.getDataChunk(c)) { if (n < cap) sizes[n] = c.get_size(); n++; free(c.get_reads()); }
   return n;
 }
+// the same walk, reporting how it ended: 0 = every file read to its end, 1 = stopped on an error (not FASTQ, a corrupt or
+// truncated compressed stream, a part size below the overhead); *nparts = parts handed out before that
+int shkh_chunk_status(const char **paths, int nfiles, int mode, uint64_t part_size, uint32_t overhead, uint64_t *nparts) {
+  std::vector<std::string> f(paths, paths + nfiles);
+  shk::seqFile_batch b(f, shk::FASTQ, mode == 1 ? shk::GZIP : mode == 2 ? shk::BZIP2 : shk::TEXT, part_size, overhead);
+  shk::chunk c;
+  uint64_t n = 0;
+  while (b.getDataChunk(c)) { n++; free(c.get_reads()); }
+  if (nparts) *nparts = n;
+  return b.bad() ? 1 : 0;
+}
 // shard tables -> the single table (see stitch.hpp)
 int shkh_stitch(const uint8_t *const *shards, const uint64_t *shard_blocks, uint32_t nshards, uint32_t qb, uint8_t *out,
                 uint64_t out_bytes) {

@@ -463,17 +463,25 @@ def test_unitig_set_invariants(shk, tmp_path, mark):
     q.free()
 
 
-@pytest.mark.parametrize("per_read,rule", [(True, 1), (False, 1), (False, 2)])
+@pytest.mark.parametrize("per_read,rule", [(True, 1), (False, 1)])
 def test_contiger_whole_pipeline_against_the_sequential_restatement(shk, tmp_path, per_read, rule):
     """seeds from reads -> walks -> queued contigs -> duplicate removal -> renumbering -> links -> unitigs.fa on the
     emulator build of the device code == the sequential restatement of the whole of Contiger
     (oracle/contiger_pipeline.cpp): canonical sequences, km, KC and the canonical link set under the read-by-read
     schedule; sequences, links and admissible km when all chunks are one batch (tests/contiger_cases.py)"""
     import contiger_cases as CC
-    fq = CC.reads(G=420, nreads=150, L=60, err=0.006, plasmid=70, seed=61)
+    fq = CC.reads(G=420, nreads=150, L=60, err=0.006, plasmid=70, seed=65)
     r = CC.run_case(lambda **kw: _ctx(shk, **kw), shk.UnitigSet, tmp_path, k=21, qb=13, fq=fq, chunk_reads=50,
                     per_read=per_read, rule=rule, max_len=4000)
     assert r["unitigs"] >= 8 and r["links"] >= 6 and r["circles"] >= 1, r
+
+
+def test_contiger_randomised_against_the_sequential_restatement(shk):
+    """tools/fuzz_contiger.py on the emulator build: random small genomes (repeats, plasmids, errors), k 21 .. 64,
+    thresholds incl. x < s (sequential schedule only) and x > s, both schedules"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_contiger.py"), "--emu", "--cases", "16", "--seed", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "16 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
 
 
 @pytest.mark.parametrize("flow", ["single", "sharded"])

@@ -525,6 +525,87 @@ def test_contiger_at_celegans_table_size(tmp_path):
     ctx.close()
 
 
+@pytest.mark.parametrize("k,qb,per_read", [(21, 17, False), (31, 17, True), (47, 17, False), (64, 18, False)])
+def test_contiger_whole_pipeline_against_the_sequential_restatement(tmp_path, k, qb, per_read):
+    """the whole of Contiger -- seeds taken from the reads, walks, queued branch contigs, duplicate removal, numbering,
+    links, unitigs.fa -- on the GPU against the sequential restatement of the whole program
+    (oracle/contiger_pipeline.cpp, tests/contiger_cases.py): canonical sequences and the canonical link set are equal;
+    km / KC are equal under the read-by-read schedule and a value some schedule of the reference gives otherwise.
+    A genome with repeats, a plasmid (pure circles), errors, N and lower-case reads; default thresholds -s 2 -x 2."""
+    import shk
+    import contiger_cases as CC
+    fq = CC.reads(G=24000 if not per_read else 6000, nreads=2600 if not per_read else 700, L=150, err=0.004, plasmid=700, seed=41)
+    r = CC.run_case(_ctx, shk.UnitigSet, tmp_path, k=k, qb=qb, fq=fq, chunk_reads=600, per_read=per_read, max_len=1 << 17)
+    assert r["unitigs"] >= 8 and r["links"] >= 8, r
+
+
+def test_contiger_randomised_against_the_sequential_restatement():
+    """tools/fuzz_contiger.py on the GPU: random genomes, k (21 .. 64), read lengths, thresholds (incl. x < s and x > s),
+    schedules"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_contiger.py"), "--cases", "40", "--seed", "9", "--scale", "12"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "40 cases, 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert "'circles': 0" not in r.stdout        # pure circles were among the cases
+
+
+def test_contiger_at_celegans_table_size_default_thresholds_against_the_restatement(tmp_path):
+    """BASELINE config 3 with the command line's DEFAULT thresholds (-s 2 -x 2): a C. elegans-sized filter (qb 29) built
+    on the GPU from 8 M reads of a 20 Mb genome, Contiger on the device over the same reads, and the sequential
+    restatement of the whole program on the CPU over the same .cqf and the same chunks. Equal: the canonical sequence set
+    and the canonical link set (hundreds of thousands of unitigs: 60x coverage leaves ~10^5 error bubbles above count 2);
+    km equal or -- where the batched schedule lets another seed find a unitig first -- admissible (sampled)."""
+    import importlib.util
+    import random
+    import unitig_compare as UC
+    import contiger_cases as CC
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_contiger", os.path.join(root, "tools", "bench_contiger.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+
+    class A:
+        genome, reads, err, k, qb, amin, xmin, max_len, batch_chunks = 20_000_000, 8_000_000, 0.00234, 47, 29, 2, 2, 1 << 26, 64
+    torch, shk, ctx, text, offs, lens, _ = bc.build(A)
+    cqf = str(tmp_path / "k47.cqf")
+    ctx.export_cqf(cqf)                       # before the walk sets traveled bits
+    out = str(tmp_path / "unitigs.fa")
+    nseeds, st, t_walk, t_write, walk_ms, prof = bc.walk(shk, ctx, text, offs, lens, A, out)
+    assert st["truncated"] == 0
+    host = text.cpu().numpy().tobytes()
+    del text
+    ctx.close()
+    k = A.k
+    q = cqflibs.oracle().load(cqf)
+    orc_fa, ost = q.contiger(host, offs, lens, k, A.amin, A.xmin, 1000000, 1, True)
+    q.free()
+    dev = UC.canonical(UC.parse(open(out, "rb").read(), k), k)
+    orc = UC.canonical(UC.parse(orc_fa, k), k, drop_invalid=True)
+    del orc_fa
+    assert dev[2] == 0
+    assert set(dev[0]) == set(orc[0]), (len(dev[0]), len(orc[0]), len(set(dev[0]) ^ set(orc[0])))
+    assert dev[1] == orc[1], (len(dev[1]), len(orc[1]), len(dev[1] ^ orc[1]))
+    assert len(dev[0]) > 50000 and sum(len(c) - k + 1 for c in dev[0]) >= 0.98 * A.genome
+    diff = [c for c in dev[0] if dev[0][c] != orc[0][c]]
+    print("unitigs", len(dev[0]), "links", len(dev[1]), "km differ", len(diff), "stale links in the restatement", orc[2], "oracle", ost)
+    assert len(diff) <= 0.25 * len(dev[0])
+    qc = cqflibs.oracle().load(cqf)
+    O = cqflibs.oracle()
+    mask = (1 << (A.qb + 8)) - 1
+
+    def count(km):
+        fh, rh = O.nthash(km, k)
+        return qc.count(min(fh, rh) & mask)
+    sk = CC.seed_kmers(host, k)
+    small = [c for c in diff if len(c) <= 1500]
+    for c in random.Random(3).sample(small, min(150, len(small))):
+        adm = UC.admissible_km(c, k, count, sk)
+        assert dev[0][c][0] in adm and orc[0][c][0] in adm, (dev[0][c], orc[0][c], sorted(adm))
+    qc.free()
+
+
 def _sha256_file(path):
     import hashlib
     h = hashlib.sha256()

@@ -4,6 +4,7 @@ import os
 import sys
 
 import cqflibs
+import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -217,3 +218,45 @@ def test_record_cut_and_malformed_input(tmp_path):
     out = (C.c_uint64 * 64)()
     n = L.shkh_chunk_sizes(arr, 1, 0, 20000, 4095, out, 64)
     assert n <= 1 and (n == 0 or out[0] == 0)                # at most the first (empty) part, then the error
+
+
+def test_chunker_fails_on_damaged_streams_and_tiny_parts(tmp_path):
+    """a truncated / corrupt .gz must end the run with an error (it used to yield empty parts forever: gzread's
+    -1 was taken for 0 bytes with the end flag never raised); a part size below the overhead is refused; a buffer shorter
+    than overhead/2 is scanned from its start instead of from a negative offset"""
+    import ctypes as C
+    import gzip
+    L = _hostlib()
+    L.shkh_chunk_status.restype = C.c_int
+    L.shkh_chunk_status.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    fq = synth.make_fastq(synth.make_genome(5000, 3), 3000, 100, 0.01, seed=4)
+
+    def status(path, mode, ps, ov):
+        arr = (C.c_char_p * 1)(str(path).encode())
+        n = C.c_uint64()
+        rc = L.shkh_chunk_status(arr, 1, mode, ps, ov, C.byref(n))
+        return rc, n.value
+    good = tmp_path / "good.fq.gz"
+    good.write_bytes(gzip.compress(fq))
+    rc, n = status(good, 1, 60000, 4000)
+    assert rc == 0 and n >= 8
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(good.read_bytes()[:len(good.read_bytes()) // 2])          # truncated in the middle of the deflate stream
+    rc, n2 = status(cut, 1, 60000, 4000)
+    assert rc == 1 and n2 < n
+    junk = tmp_path / "junk.fq.gz"
+    raw = bytearray(good.read_bytes())
+    raw[len(raw) // 2:len(raw) // 2 + 64] = bytes(64)                          # corrupt the stream
+    junk.write_bytes(bytes(raw))
+    rc, _ = status(junk, 1, 60000, 4000)
+    assert rc == 1
+    plain = tmp_path / "p.fq"
+    plain.write_bytes(fq)
+    assert status(plain, 0, 1000, 4000)[0] == 1                                # part size < overhead: refused
+    assert status(plain, 0, 4000, 4000)[0] == 0
+    L.shkh_record_cut.restype = C.c_uint64
+    L.shkh_record_cut.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32]
+    rec = b"@r1\nACGT\n+\nIIII\n"
+    buf = rec * 12
+    cutpos = L.shkh_record_cut(buf, len(buf), 65535)                           # n < overhead / 2
+    assert cutpos and cutpos % len(rec) == 0
