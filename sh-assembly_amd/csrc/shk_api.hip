@@ -323,12 +323,14 @@ extern "C" void shk_destroy(shk_ctx *c) {
 // ------------------------------------------------------------------ helpers
 // exclusive scan of in[0..n) (n on the host, or *n_dev on the device with n_max as bound)
 template <typename T>
-static int run_scan(shk_ctx *c, const T *in, uint64_t n_max, const uint64_t *n_dev, uint64_t *out) {
+static int run_scan(shk_ctx *c, const T *in, uint64_t n_max, const uint64_t *n_dev, uint64_t *out, uint64_t *sums = nullptr) {
+  // sums: n_max / SHK_SCAN_TILE + 2 words of scratch; the context's own fits the batch sizes it was created for
   ProfScope ps(c, KP_SCAN);
+  if (!sums) sums = c->d_block_sums;
   const uint32_t nb = (uint32_t)(n_max / SHK_SCAN_TILE + 1);
-  hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, c->d_block_sums);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(c->threads), 0, c->stream, c->d_block_sums, (uint64_t)nb, c->d_scalars + 2);
-  hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, c->d_block_sums,
+  hipLaunchKernelGGL((k_scan_reduce<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, sums);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(c->threads), 0, c->stream, sums, (uint64_t)nb, c->d_scalars + 2);
+  hipLaunchKernelGGL((k_scan_apply<T>), dim3(nb), dim3(c->threads), 0, c->stream, in, n_max, n_dev, sums,
                      c->d_scalars + 2, out);
   HIPCHK(hipGetLastError());
   return 0;
@@ -2115,13 +2117,31 @@ static int ug_bind(shk_unitig_set *u, shk_ctx *c, uint32_t k, uint64_t amin, uin
     if (u->c != c || u->k != k || u->amin != amin || u->max_len != max_len) return SHK_ERR_ARG;   // one filter, one set of rules
     return SHK_OK;
   }
+  // bound only once everything is allocated: a set whose first bind failed stays unbound (and can be bound again)
+  uint32_t *d_scal = nullptr, *h_scal = nullptr;
+  unsigned long long *d_stats = nullptr;
+  if (dmalloc(&d_scal, 16) || dmalloc(&d_stats, 8) || hipHostMalloc((void **)&h_scal, 64, hipHostMallocDefault) != hipSuccess ||
+      hipMemsetAsync(d_scal, 0, 16 * 4, c->stream) != hipSuccess || hipMemsetAsync(d_stats, 0, 8 * 8, c->stream) != hipSuccess) {
+    hipFree(d_scal); hipFree(d_stats); if (h_scal) hipHostFree(h_scal);
+    return SHK_ERR_HIP;
+  }
   u->c = c; u->k = k; u->amin = amin; u->max_len = max_len;
-  if (dmalloc(&u->d_scal, 16) || dmalloc(&u->d_stats, 8)) return SHK_ERR_HIP;
-  HIPCHK(hipHostMalloc((void **)&u->h_scal, 64, hipHostMallocDefault));
-  HIPCHK(hipMemsetAsync(u->d_scal, 0, 16 * 4, c->stream));
-  HIPCHK(hipMemsetAsync(u->d_stats, 0, 8 * 8, c->stream));
+  u->d_scal = d_scal; u->d_stats = d_stats; u->h_scal = h_scal;
   u->G.ncontigs = u->d_scal; u->G.next_n = u->d_scal + 1; u->G.flags = u->d_scal + 2; u->G.stats = u->d_stats;
-  return ug_reserve(u, 1024, 1024);
+  int rc = ug_reserve(u, 1024, 1024);
+  if (rc) {           // release what the half-made set holds and unbind it
+    hipStreamSynchronize(c->stream);
+    ShkUG &G = u->G;
+    hipFree(G.first_lo); hipFree(G.first_hi); hipFree(G.cur_lo); hipFree(G.cur_hi); hipFree(G.rc_lo); hipFree(G.rc_hi);
+    hipFree(G.fh); hipFree(G.rh); hipFree(G.hmin); hipFree(G.len); hipFree(G.l1); hipFree(G.cnt0); hipFree(G.state); hipFree(G.kind);
+    hipFree(G.stop); hipFree(G.mk_lo); hipFree(G.mk_hi); hipFree(G.mv); hipFree(G.ck); hipFree(G.cv);
+    hipFree(u->d_list[0]); hipFree(u->d_list[1]); hipFree(u->d_scal); hipFree(u->d_stats); hipHostFree(u->h_scal);
+    memset(&u->G, 0, sizeof(u->G));
+    u->d_list[0] = u->d_list[1] = nullptr; u->d_scal = nullptr; u->d_stats = nullptr; u->h_scal = nullptr;
+    u->cap = u->mcap = u->ccap = u->lcap = 0;
+    u->c = nullptr;
+  }
+  return rc;
 }
 
 // rounds of k_ug_walk until no contig is open; d_list[0] holds `nactive` ids
@@ -2248,7 +2268,7 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
   HIPCHK(hipSetDevice(c->dev));
   const uint32_t n = u->ncontigs;
   uint32_t *d_keep = nullptr, *d_lens = nullptr, *d_ulen = nullptr, *d_ul1 = nullptr, *d_cnt = nullptr;
-  uint64_t *d_newid = nullptr, *d_off = nullptr, *d_uoff = nullptr;
+  uint64_t *d_newid = nullptr, *d_off = nullptr, *d_uoff = nullptr, *d_sums = nullptr;
   char *d_bases = nullptr;
   int32_t *d_med = nullptr, *d_links = nullptr;
   uint64_t *m_lo = nullptr, *m_hi = nullptr; uint32_t *m_v = nullptr;
@@ -2259,7 +2279,10 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
   std::vector<int32_t> med, links;
   uint64_t nunits = 0, total = 0;
   do {
-    if ((uint64_t)n / SHK_SCAN_TILE + 2 > 8192) { rc = SHK_ERR_BATCH; break; }     // run_scan's scratch in the context
+    // the scans run over all contig ids (seeds, queued neighbours, duplicates): their block sums get scratch of their own,
+    // sized from n (the context's is sized for its key batches -- a graph of more than 16.7 M ids used to be refused here,
+    // after all the walks)
+    if (dmalloc(&d_sums, (uint64_t)n / SHK_SCAN_TILE + 8)) { rc = SHK_ERR_HIP; break; }
     if (dmalloc(&d_keep, (uint64_t)n + 1) || dmalloc(&d_lens, (uint64_t)n + 1) || dmalloc(&d_newid, (uint64_t)n + 2) || dmalloc(&d_off, (uint64_t)n + 2)) { rc = SHK_ERR_HIP; break; }
     hipLaunchKernelGGL(k_ug_check, dim3((n + 255) / 256), dim3(256), 0, c->stream, u->G, n, d_keep, d_lens);
     if (getenv("SHK_UG_DEBUG")) {   // diagnostics: contigs by kind, state and last stop reason
@@ -2272,8 +2295,13 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
       for (int kd = 0; kd < 2; kd++) for (int stt = 0; stt < 4; stt++) for (int sp = 0; sp < 8; sp++)
         if (h[kd][stt][sp]) fprintf(stderr, "SHK_UG_DEBUG %s state %d stop %d: %llu\n", kd ? "seed" : "cand", stt, sp, h[kd][stt][sp]);
       fprintf(stderr, "SHK_UG_DEBUG kept seeds %llu candidates %llu\n", kept[1], kept[0]);
+      std::vector<uint64_t> hh(n);
+      std::vector<uint32_t> hl(n);
+      hipMemcpy(hh.data(), u->G.hmin, (size_t)n * 8, hipMemcpyDeviceToHost); hipMemcpy(hl.data(), u->G.len, (size_t)n * 4, hipMemcpyDeviceToHost);
+      for (uint32_t i = 1; i < n; i++)
+        if ((hp[i] & 15) == SHK_STOP_CIRCLE) fprintf(stderr, "SHK_UG_DEBUG circle id %u state %d keep %u len %u hmin %016llx\n", i, hs[i], hkeep[i], hl[i], (unsigned long long)hh[i]);
     }
-    if (run_scan<uint32_t>(c, d_keep, n, nullptr, d_newid) || run_scan<uint32_t>(c, d_lens, n, nullptr, d_off)) { rc = SHK_ERR_HIP; break; }
+    if (run_scan<uint32_t>(c, d_keep, n, nullptr, d_newid, d_sums) || run_scan<uint32_t>(c, d_lens, n, nullptr, d_off, d_sums)) { rc = SHK_ERR_HIP; break; }
     if (hipMemcpyAsync(c->h_pinned + 45, d_newid + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipMemcpyAsync(c->h_pinned + 46, d_off + n, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { rc = SHK_ERR_HIP; break; }
@@ -2307,7 +2335,7 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
   } while (0);
   hipStreamSynchronize(c->stream);
   hipFree(d_keep); hipFree(d_lens); hipFree(d_newid); hipFree(d_off); hipFree(d_bases); hipFree(d_cnt); hipFree(d_uoff); hipFree(d_ulen);
-  hipFree(d_ul1); hipFree(d_med); hipFree(d_links); hipFree(m_lo); hipFree(m_hi); hipFree(m_v);
+  hipFree(d_ul1); hipFree(d_med); hipFree(d_links); hipFree(m_lo); hipFree(m_hi); hipFree(m_v); hipFree(d_sums);
   if (rc) { fclose(fo); return finish(c, rc); }
   // the records as the reference writes them (:606-626): ids 0-based in final numbering, successors then predecessors
   std::string line;

@@ -37,7 +37,8 @@ struct ShkUG {
   // contigs (index = contig id, ids start at 1 like the reference's contigs.resize(1))
   uint64_t *first_lo, *first_hi, *cur_lo, *cur_hi, *rc_lo, *rc_hi, *fh, *rh, *hmin;
   uint32_t *len, *l1, *cnt0;
-  uint8_t *state, *kind, *stop;      // kind: bit 0 = seed (walked both ways), bit 1 = second call running, bit 2 = hashes not yet computed
+  uint8_t *state, *kind, *stop;      // kind: bit 0 = seed (walked both ways), bit 1 = second call running, bit 2 = hashes not yet computed,
+                                     // bit 3 + bits 4-5 = the base onto RC(seed) (k_ug_emit), bit 6 = a pure circle (the circle set decides who keeps it)
   uint32_t cap;
   uint32_t *ncontigs;                // next free id
   // start-k-mer map
@@ -318,9 +319,15 @@ __global__ void __launch_bounds__(SHK_WAVE) k_ug_walk(ShkUG G, const uint32_t *a
         xc = (unsigned)__ffs((int)(cand_m & 0xFu)) - 1;
         const shk_u128 nxt = ((win << 2) | xc) & wmask;
         if (nxt == first) {
-          // a pure circle (:3176-3183): both keys go to this contig; the same circle cut elsewhere meets it in the circle set
+          // a pure circle (:3176-3183). The reference registers first k-mer and RC(last k-mer) here, keys that depend on
+          // where the seed cut the circle. Seeds of one batch that lie on the same circle all get this far at the same
+          // time, each with its own cut; their keys would then stop each other's later steps as "known nodes" and leave
+          // fragments and several rotations behind (seen on the GPU; the emulator runs workgroups one after another and
+          // never did). A pure circle has no solid neighbour outside itself, so nobody else ever asks the map for its
+          // k-mers: it registers NOTHING there and is owned through the circle set alone (minimum canonical hash over
+          // its k-mers -> smallest id); the graph pass's own map (k_ug_map2) gives the kept one its two self links.
           stop = SHK_STOP_CIRCLE;
-          if (sub == 0) ok = shk_ug_put(G, first, id, false) && shk_ug_put(G, rcw, id, false) && shk_ug_circle_put(G, hmin, id);
+          if (sub == 0) { shk_ug_circle_put(G, hmin, id); ok = true; }
         } else if (len >= max_len) {
           stop = SHK_STOP_BUFFER;
           if (sub == 0) { atomicAdd(&G.stats[2], 1ULL); ok = shk_ug_put(G, rcw, id, false); }
@@ -390,6 +397,7 @@ __global__ void __launch_bounds__(SHK_WAVE) k_ug_walk(ShkUG G, const uint32_t *a
       if (sub == 0) { G.first_lo[id] = (uint64_t)first; G.first_hi[id] = (uint64_t)(first >> 64); G.l1[id] = len; }
       continue;                                                // second call, same lanes, remaining step budget
     }
+    if (nstate == SHK_UG_CLOSED && stop == SHK_STOP_CIRCLE) kind |= 0x40u;      // owned through the circle set (k_ug_check)
     if (sub == 0) { G.state[id] = nstate; G.kind[id] = kind; }
     alive = false;
   }
@@ -406,8 +414,8 @@ __global__ void k_ug_check(ShkUG G, uint32_t n, uint32_t *keep, uint32_t *lens) 
   if (id >= 1 && G.state[id] == SHK_UG_CLOSED) {
     const shk_u128 first = ((shk_u128)G.first_hi[id] << 64) | G.first_lo[id];
     const shk_u128 rcw = ((shk_u128)G.rc_hi[id] << 64) | G.rc_lo[id];
-    kp = shk_ug_find(G, first) == id && shk_ug_find(G, rcw) == id;
-    if (kp && (G.stop[id] & 15u) == SHK_STOP_CIRCLE) kp = shk_ug_circle_find(G, G.hmin[id]) == id;
+    if (G.kind[id] & 0x40u) kp = shk_ug_circle_find(G, G.hmin[id]) == id;               // a pure circle: the circle set's owner
+    else kp = shk_ug_find(G, first) == id && shk_ug_find(G, rcw) == id;
     if (!kp) { G.state[id] = SHK_UG_CLEARED; atomicAdd(&G.stats[1], 1ULL); }
   }
   keep[id] = kp;

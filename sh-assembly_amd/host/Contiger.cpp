@@ -69,15 +69,15 @@ int main(int argc, char *argv[]) {
   }
   if (K < 0 || flist.empty() || cqf.empty()) { usage(argv[0]); return 0; }
 
-  // list of read files, relative to the list's directory (as CQF-deNoise does)
+  // list of read files, opened AS WRITTEN (relative names are relative to the working directory): the reference's
+  // Contiger hands the lines to seqFile_batch unchanged (src/contig_assembly.cpp:248-258; its help text asks for
+  // absolute names when the reads are elsewhere) -- unlike CQF-deNoise, which prefixes the list's directory
+  // (src/CQF-deNoise.cpp:59-81)
   vector<string> files;
-  string file_prefix = "";
-  auto pos = flist.find_last_of("/\\");
-  if (pos != string::npos) file_prefix = flist.substr(0, pos + 1);
   ifstream fin(flist);
   if (!fin.is_open()) { cerr << "Failed to open file: " << flist << endl; return 0; }
   string line;
-  while (getline(fin, line)) { if (line.empty()) continue; files.push_back(file_prefix + line); }
+  while (getline(fin, line)) { if (line.empty()) continue; files.push_back(line); }
   FILE_MODE ftype;
   if (fmt == 'g') ftype = GZIP; else if (fmt == 'b') ftype = BZIP2; else if (fmt == 'f') ftype = TEXT;
   else { cerr << "Unrecognized file type " << fmt << endl; return 0; }

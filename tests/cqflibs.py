@@ -233,6 +233,17 @@ class _Lib:
             n = self.L.orc_encode_counter(rem, count, out)
         return [out[i] for i in range(n)]
 
+    def seq_keys(self, seqs, k, hb):
+        """filter keys (canonical ntHash mod 2^hb) of every k-mer of every sequence, as a numpy uint64 array in order"""
+        import numpy as np
+        assert self.p == "orc_"
+        text = b"".join(b"@\n" + s + b"\n+\n\n" for s in seqs)
+        n = sum(max(0, len(s) - k + 1) for s in seqs)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        got = self.L.orc_chunk_keys(text, len(text), k, hb, out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        assert got == n, (got, n)
+        return out[:n]
+
     def chunk_keys(self, chunk: bytes, k, hb):
         assert self.p == "orc_"
         n = self.L.orc_chunk_keys(chunk, len(chunk), k, hb, None, 0)

@@ -332,9 +332,13 @@ def test_contiger_cli_unitig_set(tmp_path):
     cqf = str(tmp_path / "k47.cqf")
     q.serialize(cqf)
     out = str(tmp_path / "unitigs.fa")
-    r = subprocess.run([exe, "-k", str(k), "-i", str(tmp_path / "files.txt"), "-c", cqf, "-o", out, "--part-size", "60000",
+    # Contiger opens the list's entries as written, relative to the working directory (contig_assembly.cpp:248-258): the
+    # list lies elsewhere, its names are relative to cwd
+    (tmp_path / "lists").mkdir()
+    (tmp_path / "lists" / "files.txt").write_text("a.fq\nb.fq\n")
+    r = subprocess.run([exe, "-k", str(k), "-i", str(tmp_path / "lists" / "files.txt"), "-c", cqf, "-o", out, "--part-size", "60000",
                         "--overhead", "4000", "--batch-chunks", "3", "--max-len", str(2 * len(g) + k)],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     got = _read_unitigs(out, k)
     O = cqflibs.oracle()
@@ -439,7 +443,8 @@ def test_contiger_cli_from_gpu_built_cqf(tmp_path):
     assert r.returncode == 0, r.stderr
     out = str(tmp_path / "unitigs.fa")
     r = subprocess.run([os.path.join(bind, "Contiger"), "-k", str(k), "-i", str(tmp_path / "files.txt"), "-c", cqf, "-o", out,
-                        "--part-size", "100000", "--overhead", "4000", "--batch-chunks", "3"], capture_output=True, text=True, timeout=300)
+                        "--part-size", "100000", "--overhead", "4000", "--batch-chunks", "3"], capture_output=True, text=True, timeout=300,
+                       cwd=str(tmp_path))      # Contiger opens the names as written: relative to the working directory
     assert r.returncode == 0, r.stderr
     q = cqflibs.oracle().load(cqf)
     qb = 0
@@ -585,20 +590,27 @@ def test_contiger_at_celegans_table_size_default_thresholds_against_the_restatem
     orc = UC.canonical(UC.parse(orc_fa, k), k, drop_invalid=True)
     del orc_fa
     assert dev[2] == 0
-    assert set(dev[0]) == set(orc[0]), (len(dev[0]), len(orc[0]), len(set(dev[0]) ^ set(orc[0])))
-    assert dev[1] == orc[1], (len(dev[1]), len(orc[1]), len(dev[1] ^ orc[1]))
-    assert len(dev[0]) > 50000 and sum(len(c) - k + 1 for c in dev[0]) >= 0.98 * A.genome
-    diff = [c for c in dev[0] if dev[0][c] != orc[0][c]]
-    print("unitigs", len(dev[0]), "links", len(dev[1]), "km differ", len(diff), "stale links in the restatement", orc[2], "oracle", ost)
-    assert len(diff) <= 0.25 * len(dev[0])
-    qc = cqflibs.oracle().load(cqf)
     O = cqflibs.oracle()
+    sk = CC.seed_kmers(host, k)
+    # unitigs one side only reports: seeds whose filter key another k-mer shares (see unitig_compare.explain_one_sided)
+    one_sided = set(dev[0]) ^ set(orc[0])
+    both = set(dev[0]) & set(orc[0])
+    assert len(one_sided) <= len(both) // 500, (len(dev[0]), len(orc[0]), len(one_sided))
+    ngroups = UC.explain_one_sided(one_sided, both, k, A.qb + 8, sk, O.seq_keys)
+    dl = {l for l in dev[1] if l[0] in both and l[2] in both}
+    ol = {l for l in orc[1] if l[0] in both and l[2] in both}
+    assert dl == ol, (len(dl), len(ol), len(dl ^ ol))
+    assert len(both) > 50000 and sum(len(c) - k + 1 for c in both) >= 0.98 * A.genome
+    diff = [c for c in both if dev[0][c] != orc[0][c]]
+    print("unitigs", len(dev[0]), "links", len(dev[1]), "one-sided", len(one_sided), "in", ngroups, "groups; km differ", len(diff),
+          "stale links in the restatement", orc[2], "oracle", ost)
+    assert len(diff) <= 0.25 * len(both)
+    qc = cqflibs.oracle().load(cqf)
     mask = (1 << (A.qb + 8)) - 1
 
     def count(km):
         fh, rh = O.nthash(km, k)
         return qc.count(min(fh, rh) & mask)
-    sk = CC.seed_kmers(host, k)
     small = [c for c in diff if len(c) <= 1500]
     for c in random.Random(3).sample(small, min(150, len(small))):
         adm = UC.admissible_km(c, k, count, sk)

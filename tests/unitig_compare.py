@@ -128,3 +128,52 @@ def admissible_km(seq, k, count, seed_kmers):
             m1 = _median_int(c[:p + 1])
             out.add(_median_int([m1] * (p + 1) + c[p + 1:]))
     return out
+
+
+def explain_one_sided(extras, common, k, hb, seed_kmers, seq_keys):
+    """Unitigs only one side reports must be what the reference itself calls "possible because of hash collisions"
+    (contig_assembly.cpp:3082): the traveled bit belongs to the filter ENTRY, so a read's seed k-mer whose key another
+    k-mer shares is skipped as "already traveled" when that other k-mer was looked at first, and is walked when it was
+    not -- a matter of the schedule (read by read there, batch by batch here). What such a seed alone reaches is then
+    found by one schedule only. Accepted: every group of one-sided unitigs (joined by k-1 overlaps) holds a seed k-mer
+    whose key is also the key of a k-mer outside the group. seq_keys(seqs, k, hb) -> uint64 keys of all k-mers in order."""
+    import numpy as np
+    extras = list(extras)
+    if not extras:
+        return 0
+    # groups by k-1 overlap of ends (either strand)
+    ends = {}
+    for i, s in enumerate(extras):
+        for e in (s[:k - 1], s[-(k - 1):], rc(s)[:k - 1], rc(s)[-(k - 1):]):
+            ends.setdefault(e, set()).add(i)
+    parent = list(range(len(extras)))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for grp in ends.values():
+        g = list(grp)
+        for j in g[1:]:
+            parent[find(j)] = find(g[0])
+    groups = {}
+    for i in range(len(extras)):
+        groups.setdefault(find(i), []).append(i)
+    common_keys = np.sort(seq_keys(list(common), k, hb))
+    extra_keys = [seq_keys([s], k, hb) for s in extras]
+    for members in groups.values():
+        inside = np.concatenate([extra_keys[i] for i in members])
+        others = np.concatenate([extra_keys[i] for i in range(len(extras)) if i not in members] + [common_keys[:0]])
+        ok = False
+        for i in members:
+            s = extras[i]
+            for p in range(len(s) - k + 1):
+                km = s[p:p + k]
+                if km in seed_kmers or rc(km) in seed_kmers:
+                    key = extra_keys[i][p]
+                    j = np.searchsorted(common_keys, key)
+                    if (j < len(common_keys) and common_keys[j] == key) or (others == key).any() or (inside == key).sum() > 1:
+                        ok = True
+        assert ok, "a unitig is reported by one side only and no colliding seed explains it (len %d)" % len(extras[members[0]])
+    return len(groups)

@@ -37,7 +37,7 @@ def main():
     torch.cuda.empty_cache()
     t0 = time.perf_counter()
     r = subprocess.run([os.path.join(ROOT, "sh-assembly_amd", "bin", "Contiger"), "-k", str(K), "-i", os.path.join(d, "files.txt"), "-c", cqf,
-                        "-o", os.path.join(d, "unitigs.fa")] + args.extra.split(), capture_output=True, text=True)
+                        "-o", os.path.join(d, "unitigs.fa")] + args.extra.split(), capture_output=True, text=True, cwd=d)
     t_walk = time.perf_counter() - t0
     lens_ = []
     if r.returncode == 0:

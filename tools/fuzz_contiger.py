@@ -24,7 +24,7 @@ def main():
     tmp = pathlib.Path(tempfile.mkdtemp())
     rnd = random.Random(args.seed)
     bad = skipped = 0
-    tot = dict(unitigs=0, links=0, km_differ=0, circles=0, stale_links=0)
+    tot = dict(unitigs=0, links=0, km_differ=0, circles=0, stale_links=0, one_sided=0)
     t0 = time.time()
     for i in range(args.cases):
         k = rnd.choice([21, 25, 31, 47, 63, 64])
