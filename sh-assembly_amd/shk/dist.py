@@ -506,15 +506,28 @@ class Exchange:
     two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
     behind compute: xGMI moves 8 B per routed key while the CUs hash."""
 
-    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True):
-        dp, sc = ctx.route_words(nwords, world)
-        self.send = wrap_words(dp, nwords, device)
+    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True, local_rc=0):
+        # local_rc: the return code of the rank-local work in front of this exchange (shk_hash_chunks), 0 = fine.
+        # A rank-local failure -- there, or in shk_route_words here -- must not keep this rank out of the all-gather its
+        # peers enter: the code travels in the gathered vector (one extra column) and EVERY rank raises after the gather.
+        rc, dp, sc = int(local_rc), None, [0] * world
+        if not rc:
+            try:
+                dp, sc = ctx.route_words(nwords, world)
+            except ShkError as e:
+                rc = e.code
         self.world, self.device = world, device
         # every rank learns every bin size in one all-gather: its own receive counts and the number of pieces
-        mine = torch.tensor(sc, dtype=torch.int64, device=device)
-        allc = torch.empty((world * world,), dtype=torch.int64, device=device)
+        mine = torch.tensor(list(sc) + [rc], dtype=torch.int64, device=device)
+        allc = torch.empty((world * (world + 1),), dtype=torch.int64, device=device)
         dist.all_gather_into_tensor(allc, mine)
-        allc = allc.view(world, world).tolist()
+        allc = allc.view(world, world + 1).tolist()
+        codes = [int(row[world]) for row in allc]
+        if any(codes):
+            bad = next(p for p in range(world) if codes[p])
+            raise ShkError(codes[bad], "rank %d failed in front of the exchange (libshk error %d); raised on every rank" % (bad, codes[bad]))
+        allc = [row[:world] for row in allc]
+        self.send = wrap_words(dp, nwords, device)
         rc = [allc[p][rank] for p in range(world)]
         mx = max(max(row) for row in allc)
         # every rank sees every bin size: a shard that would receive more than it can stage fails on ALL ranks here
@@ -558,6 +571,22 @@ class Exchange:
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
         return self.recv
+
+
+def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=False, text_bytes=None, async_op=True):
+    """shk_hash_chunks + Exchange with the rank-local failure of either carried to every rank (see Exchange)"""
+    rc, nw = 0, 0
+    try:
+        _, nw = ctx.hash_chunks(text, offs, lens, on_device=on_device, text_bytes=text_bytes)
+    except ShkError as e:
+        rc = e.code
+    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc)
+
+
+def stage_received(ctx, st, recv):
+    """shk_stage_words in front of a collective decision: a rank-local failure is parked in the shard state and shown
+    to the peers by the next all-reduce (sharded_count raises it on every rank)"""
+    _local(st, lambda: ctx.stage_words(recv.data_ptr(), recv.numel()))
 
 
 def route_words(ctx, nwords, hb, world, rank, device):

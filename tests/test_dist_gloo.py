@@ -160,3 +160,45 @@ def test_one_pass_points_make_the_shards_the_single_table(world, tmp_path, monke
     o.serialize(single)
     assert open(out_path, "rb").read() == open(single, "rb").read()
     o.free()
+
+
+def _failing_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "sh-assembly_amd"))
+    import shk
+    from shk import dist as shkdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    # rank 1's batch holds more k-mers than its context can take (max_batch_keys): shk_hash_chunks fails THERE only
+    fq, (offs, lens) = _data(rank, (24, 6) if rank == 0 else (90, 30))
+    ctx = shk.Context(qb=QB, k=K, min_denoise_len=ML, max_batch_bytes=1 << 20, max_batch_keys=2048,
+                      shard_index=rank, num_shards=world, threads_per_group=64, hash_groups=2, lib_path=EMU)
+    got = None
+    try:
+        ex = shkdist.hash_and_exchange(ctx, fq, offs, lens, QB + 8, world, rank, dev)
+        ex.wait()
+    except shk.ShkError as e:
+        got = e.code
+    q.put((rank, got))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_in_front_of_the_exchange_is_raised_on_every_rank():
+    """a rank whose hash / route call fails must still enter the exchange's all-gather, and every rank must see
+    the failure -- otherwise the peers wait in the collective until the backend's timeout"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29600 + (os.getpid() * 7 + 11) % 300
+    procs = [ctxm.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] is not None and res[0][1] == res[1][1] and res[0][1] < 0, res
