@@ -103,7 +103,9 @@ int shk_create(const shk_config *cfg, shk_ctx **out);
 void shk_destroy(shk_ctx *ctx);
 
 /* Count every k-mer of `nchunks` FASTQ chunks. chunk_off/chunk_len index into `text`
- * (text_on_device != 0: `text` is a device pointer that stays valid until the call returns).
+ * (text_on_device != 0: `text` is a device pointer, 16-byte aligned, that stays valid until the call returns; the
+ * kernels read the text in aligned 16-byte units, so the allocation must be readable up to the next multiple of 16
+ * behind text + text_bytes -- hipMalloc'ed buffers always are).
  * Chunks are the units after which the reference tests its deNoise trigger; rounds fire
  * inside the call exactly where the t = 1 reference would fire them. */
 int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,

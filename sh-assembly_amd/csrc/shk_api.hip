@@ -438,7 +438,9 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
     }
     { ProfScope ps(c, KP_RP_SCATTER);
       ShkRpLevel lvl = c->lv[l];
+#ifdef SHK_DIAGNOSTICS   // timing ablations give INVALID results: compiled into diagnostic builds only (make DIAG=1)
       if (const char *e = getenv("SHK_RP_ABLATE")) lvl.ablate = (uint32_t)atoi(e);
+#endif
       if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
         hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
                            c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err);
@@ -488,7 +490,10 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->words = reinterpret_cast<const uint32_t *>(words); A->region_base = c->d_base[c->nlevels];
   A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
+  A->ablate = 0;
+#ifdef SHK_DIAGNOSTICS   // timing ablations give INVALID results: compiled into diagnostic builds only (make DIAG=1)
   { const char *ab = getenv("SHK_ABLATE"); A->ablate = ab ? (uint32_t)atoi(ab) : 0; }
+#endif
   A->lb_agg = c->d_lb_agg; A->lb_incl = c->d_lb_incl;
   { const char *sp = getenv("SHK_STAMPS");    // diagnostics: "fused" = only the one-pass deNoise launches, "plain" = all the others, else all
     A->dbg = (sp && strcmp(sp, "fused") != 0) ? (unsigned long long *)(c->d_scalars + 16) : nullptr; }
@@ -1661,6 +1666,7 @@ extern "C" int shk_insert_counted(shk_ctx *c, const uint64_t *keys, const uint64
   { const uint64_t cap = c->cfg.max_batch_keys / 2 > 0 ? c->cfg.max_batch_keys / 2 : 1; if (slice > cap) slice = cap; }
   if (dmalloc(&doff, slice + 2) || dmalloc(&dnw, slice + 2)) return SHK_ERR_HIP;
   c->counted = 1;
+  struct CountedScope { shk_ctx *c; ~CountedScope() { c->counted = 0; } } counted_scope{c};   // every exit, incl. HIPCHK's
   uint64_t done = 0;
   while (done < n && !rc) {
     const uint64_t m = n - done < slice ? n - done : slice;
