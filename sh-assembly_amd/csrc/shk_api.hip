@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 #include "kmer_kernels.hip"
+#include "roll_kernels.hip"
 #include "partition_kernels.hip"
 #include "cqf_kernels.hip"
 #include "merge2_kernels.hip"
@@ -26,12 +27,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_ROLL_HIST, KP_ROLL_SCATTER, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc", "k_roll_hist", "k_roll_scatter"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -407,17 +408,56 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   return SHK_OK;
 }
 
+// text + chunk table -> key words in d_words[0], partitioned by the first region digit; d_base[1] = bucket bases,
+// d_scalars[1] = #words (roll_kernels.hip). For contexts with at least two partition levels.
+static bool roll_path(const shk_ctx *c) { return c->nlevels >= 2 && !getenv("SHK_NO_ROLL"); }
+static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
+  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+  const uint8_t *dtext;
+  uint64_t nreads;
+  { int rc = parse_stage(c, text, on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads); if (rc) return rc; }
+  const uint64_t P = 1ULL << c->lv[0].bits;
+  HIPCHK(hipMemsetAsync(c->d_hist[0], 0, P * 8, c->stream));
+  ShkRollArgs A;
+  A.text = dtext; A.safe_end = (text_bytes + 15) & ~15ULL;
+  A.rd_start = c->d_rd_start; A.rd_end = c->d_rd_end; A.nreads_p = c->d_scalars + 0; A.rd_chunk = c->d_rd_chunk;
+  A.chunk_first = chunk_first; A.chunk_mul = chunk_mul; A.k = c->cfg.k; A.hb = c->cfg.hb; A.q_lo = c->q_lo;
+  A.dig_shift = c->lv[0].shift; A.dig_bits = c->lv[0].bits;
+  A.hist = c->d_hist[0]; A.cursor = c->d_cursor; A.out = c->d_words[0]; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
+  { ProfScope ps(c, KP_ROLL_HIST);
+    const uint64_t blocks = nreads / 256 + 1;
+    hipLaunchKernelGGL(k_roll_hist, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, c->stream, A); }
+  // bucket bases = exclusive scan of the digit counts; its total is the number of key words
+  if (run_scan<uint64_t>(c, c->d_hist[0], P, nullptr, c->d_base[1])) return SHK_ERR_HIP;
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->d_base[1] + P, 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[1], P * 8, hipMemcpyDeviceToDevice, c->stream));
+  { ProfScope ps(c, KP_ROLL_SCATTER);
+    if (c->threads >= 512) {
+      const uint64_t blocks = nreads / 1024 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<1024>), dim3((uint32_t)(blocks < 512 ? blocks : 512)), dim3(1024), 0, c->stream, A);
+    } else {          // (small workgroups: the CPU emulator build of the tests)
+      const uint64_t blocks = nreads / 64 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<64>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
+    } }
+  HIPCHK(hipGetLastError());
+  return SHK_OK;
+}
+
 // words in d_words[src] (count in d_scalars[1], bound nmax) -> sorted by region in
 // d_words[*dst]; region offsets in d_base[nlevels]
 // (ext != null: the first level reads the caller's buffer instead of d_words[src])
-static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr, bool hist0_ready = false) {
+// first_level = 1: the words in d_words[src] are partitioned by the first digit already and d_base[1] holds the bucket
+// bases (roll_stage)
+static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr, bool hist0_ready = false,
+                           uint32_t first_level = 0) {
   const uint64_t *n_p = c->d_scalars + 1;
   { ProfScope ps(c, KP_RP_PREP);
     hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]); }
   const uint32_t nwin = (uint32_t)(nmax / SHK_RP_TILE + 1);
   const uint64_t *in = ext ? ext : c->d_words[src];
   int cur = ext ? 1 : src;   // the buffer `in` occupies (an external source leaves both free: write to d_words[0] first)
-  for (uint32_t l = 0; l < c->nlevels; l++) {
+  for (uint32_t l = first_level; l < c->nlevels; l++) {
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
     { ProfScope ps(c, KP_RP_PREP);
       hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
@@ -1174,7 +1214,9 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   shk_batch_stats st;
   memset(&st, 0, sizeof(st));
   HIPCHK(hipSetDevice(c->dev));
-  int rc = hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1, true);
+  const bool roll = roll_path(c);
+  int rc = roll ? roll_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1)
+                : hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1, true);
   if (rc) return finish(c, rc);
   uint32_t bits = 0;
   HIPCHK(hipMemcpyAsync(c->h_pinned + 42, c->d_scalars + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1183,7 +1225,8 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   const uint64_t nwords = c->h_pinned[42];
   if (nwords > c->cfg.max_batch_keys) { prof_collect(c); return SHK_ERR_BATCH; }
   int dst = 0;
-  rc = partition_stage(c, 0, nwords, &dst, nullptr, true);   // the hash kernel already counted the first level's digits
+  // (the roll kernels leave the words partitioned by the first digit; the hash kernel has counted the first level's digits)
+  rc = roll ? partition_stage(c, 0, nwords, &dst, nullptr, false, 1) : partition_stage(c, 0, nwords, &dst, nullptr, true);
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
