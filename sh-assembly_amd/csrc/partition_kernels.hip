@@ -237,6 +237,6 @@ __global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint
         out[gbase[d] + (i - lbase[d])] = x;
       }
     }
-    __syncthreads();
+    shk_lds_barrier();             // (LDS only: the runs just written drain to HBM behind it)
   }
 }

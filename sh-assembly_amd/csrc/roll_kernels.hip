@@ -34,72 +34,157 @@ struct ShkRollArgs {
   uint32_t *err;
 };
 
-// rows of the two tables in LDS: in[code] = {seed, rol(seedc, k-1)}, out[code] = {rol(seed, k), ror1(seedc)}; code 4 = 0
+// The two tables in LDS, indexed by the raw BYTE (no code lookup in between): row c of `in` = {seed[c], rol(seedc[c], k-1)},
+// row c of `out` = {rol(seed[c], k), ror1(seedc[c])}; every byte that is not a base (either case) has zero rows.
+struct ShkRollRow { uint64_t f, r; };
 struct ShkRollTabs {
-  uint64_t in_f[8], in_r[8], out_f[8], out_r[8];
-  uint8_t code[256];
+  ShkRollRow in[256], out[256];
 };
 __device__ __forceinline__ void shk_roll_tabs_init(ShkRollTabs *t, uint32_t k) {
   const uint64_t sf[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL};  // A C G T, nthash.hpp:24-27
-  for (uint32_t i = threadIdx.x; i < 8; i += blockDim.x) {
-    const uint64_t f = i < 4 ? sf[i] : 0, c = i < 4 ? sf[3 - i] : 0;     // complement: A<->T, C<->G (cpOff, nthash.hpp:15)
-    t->in_f[i] = f; t->in_r[i] = shk_rol64(c, k - 1);
-    t->out_f[i] = shk_rol64(f, k); t->out_r[i] = shk_ror64(c, 1);
-  }
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
     const uint32_t u = i & 0xDF;
-    t->code[i] = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+    const int b = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : -1;
+    const uint64_t f = b >= 0 ? sf[b] : 0, c = b >= 0 ? sf[3 - b] : 0;   // complement: A<->T, C<->G (cpOff, nthash.hpp:15)
+    t->in[i].f = f; t->in[i].r = shk_rol64(c, k - 1);
+    t->out[i].f = shk_rol64(f, k); t->out[i].r = shk_ror64(c, 1);
   }
+}
+// rotations by one as funnel shifts of the halves (v_alignbit_b32 each; the 64-bit shifts run at a quarter of the rate)
+__device__ __forceinline__ uint64_t shk_rol1(uint64_t x) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  return ((uint64_t)((hi << 1) | (lo >> 31)) << 32) | ((lo << 1) | (hi >> 31));
+}
+__device__ __forceinline__ uint64_t shk_ror1(uint64_t x) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  return ((uint64_t)((hi >> 1) | (lo << 31)) << 32) | ((lo >> 1) | (hi << 31));
 }
 
 // 16 bytes at `p` (any alignment); bytes at or behind safe_end read as 0
-__device__ __forceinline__ uint4 shk_load16(const uint8_t *text, uint64_t at, uint64_t safe_end) {
-  uint4 v;
+struct ShkQuad { uint32_t x, y, z, w; };      // (a plain aggregate: HIP's uint4 is a union inside, which keeps the state out of registers)
+__device__ __forceinline__ ShkQuad shk_quad(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { ShkQuad q = {x, y, z, w}; return q; }
+__device__ __forceinline__ ShkQuad shk_load16(const uint8_t *text, uint64_t at, uint64_t safe_end) {
+  ShkQuad v;
   if (at + 16 <= safe_end) { __builtin_memcpy(&v, text + at, 16); return v; }
   uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
   for (int j = 0; j < 16; j++)
     if (at + j < safe_end) w[j >> 2] |= (uint32_t)text[at + j] << (8 * (j & 3));
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  return shk_quad(w[0], w[1], w[2], w[3]);
 }
 
-// One thread's place in its read (reads_to_kmers' loop state)
+// One thread's place in its read (reads_to_kmers' loop state). The text is fetched 64 bytes per stream at a time (four
+// 16-byte loads issued together, every fourth round): with one load per round each 128-byte line came up from L2 once
+// per 16 bytes used -- the lanes of a wave read 64 different lines, and no line survives in the CU's L1 until its
+// owner's next round -- and the kernels ran at the speed of that traffic, not of their arithmetic.
+#define SHK_ROLL_QUADS 4
 struct ShkRollState {
   uint64_t st;        // text offset of the read's first base
   uint32_t len;       // bases
   uint32_t i;         // next base to take
   uint32_t fill;      // bases of the current (sub)read taken so far, saturating at k
   uint64_t fh, rh;
+  ShkQuad i0_, i1_, i2_, i3_, o0_, o1_, o2_, o3_;      // bytes [i0b, i0b + 64) of the read and the 64 bytes k further back
 };
+// quad p of four (by masks: a chain of selects over neighbouring fields is turned into an indexed load, and the whole
+// state then lives in scratch memory)
+__device__ __forceinline__ ShkQuad shk_pick_quad(const ShkQuad &a, const ShkQuad &b, const ShkQuad &c, const ShkQuad &d, uint32_t p) {
+  const uint32_t m0 = 0u - (uint32_t)(p == 0), m1 = 0u - (uint32_t)(p == 1), m2 = 0u - (uint32_t)(p == 2), m3 = 0u - (uint32_t)(p == 3);
+  ShkQuad v;
+  v.x = (a.x & m0) | (b.x & m1) | (c.x & m2) | (d.x & m3);
+  v.y = (a.y & m0) | (b.y & m1) | (c.y & m2) | (d.y & m3);
+  v.z = (a.z & m0) | (b.z & m1) | (c.z & m2) | (d.z & m3);
+  v.w = (a.w & m0) | (b.w & m1) | (c.w & m2) | (d.w & m3);
+  return v;
+}
 
 // Takes the next (at most 16) bases of the read; calls emit(j, key) for the k-mer that step j (0..15, a compile-time
 // constant after unrolling) completes. Returns false when the read is used up.
-template <typename Emit>
+// Two forms of the same recurrence. The STRAIGHT one runs when the thread is in the middle of a (sub)read: its window is
+// full, the 16 bytes ahead hold no 'N', and the base that leaves lies in the second load -- no branches, the state is
+// updated unconditionally (behind the end of the read it is never looked at again) and only the emission is predicated.
+// The GENERAL one is reads_to_kmers step by step (first window, restart behind an 'N').
+// NQ = 16-byte quads fetched at a time per stream (4 in the histogram pass; the scatter pass, whose 16 keys per thread
+// wait in registers for their window, has room for 2)
+template <int NQ, typename Emit>
 __device__ __forceinline__ bool shk_roll_round(const ShkRollTabs *T, const uint8_t *text, uint64_t safe_end, ShkRollState &s,
                                                uint32_t k, uint64_t mask, Emit emit) {
   if (s.i >= s.len) return false;
-  const uint4 vin = shk_load16(text, s.st + s.i, safe_end);
-  // the base that leaves the window k steps behind; needed only once a window is full, i.e. never in front of the read
-  const uint4 vout = s.i >= k ? shk_load16(text, s.st + s.i - k, safe_end) : make_uint4(0, 0, 0, 0);
+  const uint32_t ph = (s.i / SHK_ROLL_STEPS) % NQ;
+  if (ph == 0) {
+    // the base that leaves the window lies k steps behind; it is needed only once a window is full, i.e. never in
+    // front of the read
+#define SHK_ROLL_LOAD(Q, IN, OUT) { const uint32_t at = s.i + SHK_ROLL_STEPS * Q; \
+      IN = at < s.len ? shk_load16(text, s.st + at, safe_end) : shk_quad(0, 0, 0, 0); \
+      OUT = (at >= k && at < s.len) ? shk_load16(text, s.st + at - k, safe_end) : shk_quad(0, 0, 0, 0); }
+    SHK_ROLL_LOAD(0, s.i0_, s.o0_)
+    if (NQ > 1) SHK_ROLL_LOAD(1, s.i1_, s.o1_)
+    if (NQ > 2) { SHK_ROLL_LOAD(2, s.i2_, s.o2_) SHK_ROLL_LOAD(3, s.i3_, s.o3_) }
+#undef SHK_ROLL_LOAD
+  }
+  ShkQuad vin, vout;
+  if (NQ == 1) { vin = s.i0_; vout = s.o0_; }
+  else if (NQ == 2) { vin = shk_pick_quad(s.i0_, s.i1_, s.i0_, s.i1_, ph); vout = shk_pick_quad(s.o0_, s.o1_, s.o0_, s.o1_, ph); }
+  else { vin = shk_pick_quad(s.i0_, s.i1_, s.i2_, s.i3_, ph); vout = shk_pick_quad(s.o0_, s.o1_, s.o2_, s.o3_, ph); }
   const uint32_t win[4] = {vin.x, vin.y, vin.z, vin.w}, wout[4] = {vout.x, vout.y, vout.z, vout.w};
   const uint32_t i0 = s.i;
+  uint32_t anyN = 0;
 #pragma unroll
-  for (int j = 0; j < SHK_ROLL_STEPS; j++) {
-    if (i0 + j < s.len) {
-      const uint32_t cin = (win[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-      if (s.fill >= k && cin == 'N') {
-        // the reference restarts behind an 'N' it meets at an index >= k of the (sub)read (CQF_mt.h:672-676)
-        s.fill = 0; s.fh = 0; s.rh = 0;
-      } else {
-        const uint32_t ci = T->code[cin];
-        uint64_t f = shk_rol64(s.fh, 1) ^ T->in_f[ci], r = shk_ror64(s.rh, 1) ^ T->in_r[ci];
-        if (s.fill >= k) {
-          // (i0 + j >= k here: the out byte lies k bases back, in vout when i0 >= k, else in vin itself)
-          const uint32_t cout = i0 >= k ? (wout[j >> 2] >> (8 * (j & 3))) & 0xFFu : text[s.st + i0 + j - k];
-          const uint32_t co = T->code[cout];
-          f ^= T->out_f[co]; r ^= T->out_r[co];
-        } else s.fill++;
-        s.fh = f; s.rh = r;
-        if (s.fill >= k) emit(j, (f < r ? f : r) & mask);
+  for (int q = 0; q < 4; q++) {
+    const uint32_t x = win[q] ^ 0x4E4E4E4Eu;              // a zero byte = an 'N'
+    anyN |= (x - 0x01010101u) & ~x & 0x80808080u;
+  }
+  if (s.fill >= k && i0 >= k && !anyN) {
+    uint64_t fh = s.fh, rh = s.rh;
+    const auto step = [&](int j, bool whole) {
+      const int sh = 8 * (j & 3) - 4;                      // byte j of its word, times sizeof(ShkRollRow)
+      const uint32_t oi = (sh < 0 ? win[j >> 2] << 4 : win[j >> 2] >> sh) & 0xFF0u;
+      const uint32_t oo = (sh < 0 ? wout[j >> 2] << 4 : wout[j >> 2] >> sh) & 0xFF0u;
+      const ShkRollRow ri = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->in) + oi);
+      const ShkRollRow ro = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->out) + oo);
+      fh = shk_rol1(fh) ^ ri.f ^ ro.f;
+      rh = shk_ror1(rh) ^ ri.r ^ ro.r;
+      if (whole || i0 + j < s.len) emit(j, (fh < rh ? fh : rh) & mask);
+    };
+    if (i0 + SHK_ROLL_STEPS <= s.len) {                    // (all but a read's last round: nothing is predicated)
+#pragma unroll
+      for (int j = 0; j < SHK_ROLL_STEPS; j++) step(j, true);
+    } else {
+#pragma unroll
+      for (int j = 0; j < SHK_ROLL_STEPS; j++) step(j, false);
+    }
+    s.fh = fh; s.rh = rh;
+  } else if (s.fill + SHK_ROLL_STEPS < k && i0 + SHK_ROLL_STEPS <= s.len) {
+    // inside the first window of a (sub)read, which the reference hashes without looking at it: sixteen bases go in,
+    // nothing comes out
+    uint64_t fh = s.fh, rh = s.rh;
+#pragma unroll
+    for (int j = 0; j < SHK_ROLL_STEPS; j++) {
+      const int sh = 8 * (j & 3) - 4;
+      const uint32_t oi = (sh < 0 ? win[j >> 2] << 4 : win[j >> 2] >> sh) & 0xFF0u;
+      const ShkRollRow ri = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->in) + oi);
+      fh = shk_rol1(fh) ^ ri.f;
+      rh = shk_ror1(rh) ^ ri.r;
+    }
+    s.fh = fh; s.rh = rh; s.fill += SHK_ROLL_STEPS;
+  } else {
+#pragma unroll
+    for (int j = 0; j < SHK_ROLL_STEPS; j++) {
+      if (i0 + j < s.len) {
+        const uint32_t cin = (win[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (s.fill >= k && cin == 'N') {
+          // the reference restarts behind an 'N' it meets at an index >= k of the (sub)read (CQF_mt.h:672-676)
+          s.fill = 0; s.fh = 0; s.rh = 0;
+        } else {
+          uint64_t f = shk_rol1(s.fh) ^ T->in[cin].f, r = shk_ror1(s.rh) ^ T->in[cin].r;
+          if (s.fill >= k) {
+            // (i0 + j >= k here: the base k back lies in vout when i0 >= k, else within this read's first bytes)
+            const uint32_t cout = i0 >= k ? (wout[j >> 2] >> (8 * (j & 3))) & 0xFFu : text[s.st + i0 + j - k];
+            f ^= T->out[cout].f; r ^= T->out[cout].r;
+          } else s.fill++;
+          s.fh = f; s.rh = r;
+          if (s.fill >= k) emit(j, (f < r ? f : r) & mask);
+        }
       }
     }
   }
@@ -107,8 +192,10 @@ __device__ __forceinline__ bool shk_roll_round(const ShkRollTabs *T, const uint8
   return true;
 }
 
+// first-level digit of a key (masked to hb bits). The context's first quotient is a multiple of the region size, so
+// region = ((key >> 8) - q_lo) >> 8 = (key >> 16) - (q_lo >> 8), and its low 32 bits are all there is (regions < 2^25)
 __device__ __forceinline__ uint32_t shk_roll_digit(uint64_t key, const ShkRollArgs &A) {
-  const uint32_t region = (uint32_t)(((key >> 8) - A.q_lo) >> SHK_REGION_LOG2);
+  const uint32_t region = (uint32_t)(key >> 16) - (uint32_t)(A.q_lo >> 8);
   return (region >> A.dig_shift) & ((1u << A.dig_bits) - 1);
 }
 
@@ -127,8 +214,9 @@ __global__ void __launch_bounds__(256) k_roll_hist(ShkRollArgs A) {
     const uint64_t st = A.rd_start[r], en = A.rd_end[r];
     if (en - st > 65535) { atomicOr(A.err, SHK_E_BAD_FASTQ); continue; }     // SHK_MAX_READ
     if (en - st < A.k) continue;
-    ShkRollState s = {st, (uint32_t)(en - st), 0, 0, 0, 0};
-    while (shk_roll_round(&T, A.text, A.safe_end, s, A.k, mask, [&](int, uint64_t key) { atomicAdd(&lh[shk_roll_digit(key, A)], 1u); })) {}
+    ShkRollState s;
+    s.st = st; s.len = (uint32_t)(en - st); s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
+    while (shk_roll_round<4>(&T, A.text, A.safe_end, s, A.k, mask, [&](int, uint64_t key) { atomicAdd(&lh[shk_roll_digit(key, A)], 1u); })) {}
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
@@ -136,7 +224,7 @@ __global__ void __launch_bounds__(256) k_roll_hist(ShkRollArgs A) {
 }
 
 // pass 2: the keys again, straight into their buckets. THREADS x 16 keys per window.
-template <int THREADS>
+template <int THREADS, int NQ>
 __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
   constexpr uint32_t TILE = THREADS * SHK_ROLL_STEPS;
   __shared__ ShkRollTabs T;
@@ -151,7 +239,8 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
   const uint64_t mask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
   const uint64_t stride = (uint64_t)gridDim.x * THREADS;
   uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-  ShkRollState s = {0, 0, 0, 0, 0, 0};
+  ShkRollState s;
+  s.st = 0; s.len = 0; s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
   uint64_t tag = 0;
   bool have = false;
   for (;;) {
@@ -159,7 +248,7 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
     while (!have && r < nreads) {
       const uint64_t st = A.rd_start[r], en = A.rd_end[r];
       if (en - st <= 65535 && en - st >= A.k) {
-        s = {st, (uint32_t)(en - st), 0, 0, 0, 0};
+        s.st = st; s.len = (uint32_t)(en - st); s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
         tag = (uint64_t)(A.chunk_first + A.rd_chunk[r] * A.chunk_mul) << A.hb;
         have = true;
       }
@@ -167,15 +256,13 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
     }
     for (uint32_t d = threadIdx.x; d < P; d += THREADS) lh[d] = 0;
     if (threadIdx.x == 0) any_left = 0;
-    __syncthreads();
+    shk_lds_barrier();             // (the previous window's runs keep draining to HBM while this one is hashed)
     uint64_t w[SHK_ROLL_STEPS];
-    uint32_t dr[SHK_ROLL_STEPS];
     uint32_t vm = 0;               // steps that completed a k-mer
     if (have) {
-      have = shk_roll_round(&T, A.text, A.safe_end, s, A.k, mask, [&](int j, uint64_t key) {
-        const uint32_t d = shk_roll_digit(key, A);
+      have = shk_roll_round<NQ>(&T, A.text, A.safe_end, s, A.k, mask, [&](int j, uint64_t key) {
         w[j] = key | tag;
-        dr[j] = (d << 16) | atomicAdd(&lh[d], 1u);
+        atomicAdd(&lh[shk_roll_digit(key, A)], 1u);
         vm |= 1u << j;
       });
       if (have && s.i >= s.len) have = false;
@@ -183,7 +270,9 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
     if (have || r < nreads) any_left = 1;
     __syncthreads();
     const bool more = any_left != 0;
-    // exclusive scan of the digit counts, one reservation per digit and window
+    // exclusive scan of the digit counts, one reservation per digit and window. lbase[d] then serves as the digit's
+    // cursor inside the window (the keys' ranks are handed out when they are staged: no rank waits in a register),
+    // gbase[d] = where the digit's run goes, minus its place in the window
     uint32_t carry = 0;
     for (uint32_t d0 = 0; d0 < P; d0 += THREADS) {
       const uint32_t d = d0 + threadIdx.x;
@@ -191,7 +280,7 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
       const uint32_t ex = shk_block_exscan(v, &tot, scratch);
       if (d < P) {
         lbase[d] = carry + ex;
-        gbase[d] = v ? atomicAdd((unsigned long long *)&A.cursor[d], (unsigned long long)v) : 0;
+        gbase[d] = (v ? atomicAdd((unsigned long long *)&A.cursor[d], (unsigned long long)v) : 0) - (carry + ex);
       }
       carry += tot;
     }
@@ -199,15 +288,15 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
     const uint32_t cnt = carry;
 #pragma unroll
     for (int u = 0; u < SHK_ROLL_STEPS; u++)
-      if ((vm >> u) & 1u) stage[lbase[dr[u] >> 16] + (dr[u] & 0xFFFFu)] = w[u];
+      if ((vm >> u) & 1u) stage[atomicAdd(&lbase[shk_roll_digit(A.hb >= 64 ? w[u] : (w[u] & mask), A)], 1u)] = w[u];
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) {
       const uint64_t x = stage[i];
-      const uint32_t d = shk_roll_digit(A.hb >= 64 ? x : (x & ((1ULL << A.hb) - 1)), A);
-      const uint64_t at = gbase[d] + (i - lbase[d]);
+      const uint32_t d = shk_roll_digit(A.hb >= 64 ? x : (x & mask), A);
+      const uint64_t at = gbase[d] + i;
       if (at < A.cap) A.out[at] = x; else atomicOr(A.err, SHK_E_KEYS_FULL);
     }
-    __syncthreads();
+    shk_lds_barrier();
     if (!more) break;
   }
 }

@@ -410,7 +410,7 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
 
 // text + chunk table -> key words in d_words[0], partitioned by the first region digit; d_base[1] = bucket bases,
 // d_scalars[1] = #words (roll_kernels.hip). For contexts with at least two partition levels.
-static bool roll_path(const shk_ctx *c) { return c->nlevels >= 2 && !getenv("SHK_NO_ROLL"); }
+static bool roll_path(const shk_ctx *c) { return c->nlevels >= 2 && (c->q_lo & (SHK_REGION - 1)) == 0 && !getenv("SHK_NO_ROLL"); }
 static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
                       const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
   if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
@@ -433,12 +433,19 @@ static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->d_base[1] + P, 8, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[1], P * 8, hipMemcpyDeviceToDevice, c->stream));
   { ProfScope ps(c, KP_ROLL_SCATTER);
-    if (c->threads >= 512) {
+    const char *nqe = getenv("SHK_ROLL_NQ");            // (measurement: 16-byte quads fetched at a time per stream)
+    const int nq = nqe ? atoi(nqe) : 1;
+    if (c->threads >= 512 && getenv("SHK_ROLL_512")) {     // (measurement: 8192-key windows)
+      const uint64_t blocks = nreads / 512 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<512, 4>), dim3((uint32_t)(blocks < 1024 ? blocks : 1024)), dim3(512), 0, c->stream, A);
+    } else if (c->threads >= 512) {
       const uint64_t blocks = nreads / 1024 + 1;
-      hipLaunchKernelGGL((k_roll_scatter<1024>), dim3((uint32_t)(blocks < 512 ? blocks : 512)), dim3(1024), 0, c->stream, A);
+      const dim3 grid((uint32_t)(blocks < 512 ? blocks : 512));
+      if (nq == 1) hipLaunchKernelGGL((k_roll_scatter<1024, 1>), grid, dim3(1024), 0, c->stream, A);
+      else hipLaunchKernelGGL((k_roll_scatter<1024, 2>), grid, dim3(1024), 0, c->stream, A);
     } else {          // (small workgroups: the CPU emulator build of the tests)
       const uint64_t blocks = nreads / 64 + 1;
-      hipLaunchKernelGGL((k_roll_scatter<64>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
+      hipLaunchKernelGGL((k_roll_scatter<64, 4>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
     } }
   HIPCHK(hipGetLastError());
   return SHK_OK;

@@ -60,6 +60,19 @@ __device__ __forceinline__ uint64_t shk_ror64(uint64_t v, unsigned s) {
 // (SHK_RP_TILE): 8192 made them slower.
 #define SHK_RP_TILE0_LOG2 14
 
+// Workgroup barrier that orders LDS accesses only: global stores issued before it may still be in flight behind it (a
+// __syncthreads() waits for them too: vmcnt(0)). For the scatter kernels, whose windows reuse LDS buffers while the runs
+// they have just written drain to HBM.
+__device__ __forceinline__ void shk_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+  __syncthreads();
+#endif
+}
+
 // ---- wave scans (64 lanes, shuffle based)
 // LDS writes of this wave's lanes become visible to its other lanes (a barrier among the 64 lanes only)
 __device__ __forceinline__ void shk_wave_sync() {
