@@ -104,6 +104,75 @@ def gen_batch_torch(torch, genome, nreads, L, err, first_id, seed, device):
     return out.reshape(-1)
 
 
+def csrc_sha256():
+    """hash of the kernel sources: the committed PMC traffic figures are only quoted for the code they were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sh-assembly_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def secondary_host_text(torch, shk, new_ctx, texts, offs, lens, steps=4):
+    """PCIe-inclusive rate: the same batches handed over in pinned HOST memory, uploads overlapped with the previous
+    batch's counting (shk_upload_text). Never the headline value. A scratch filter, `steps` batches."""
+    n = min(steps, len(texts))
+    host = [t.cpu().pin_memory() for t in texts[:n]]
+    ctx = new_ctx(host_text_bytes=int(host[0].numel()) + 4096)
+    up = {0: ctx.upload_text(host[0].data_ptr(), host[0].numel())}
+    kmers = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(n):
+        dptr = up.pop(s)
+        if s + 1 < n:
+            up[s + 1] = ctx.upload_text(host[s + 1].data_ptr(), host[s + 1].numel())
+        kmers += ctx.count_chunks(dptr, offs, lens, on_device=True, text_bytes=host[s].numel())["kmers"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"what": "same batches from pinned host memory, upload of batch s+1 overlapped with counting batch s (PCIe-inclusive; never `value`)",
+            "steps": n, "value": kmers / dt, "unit": "k-mers/s", "ms_per_step": dt / n * 1e3}
+
+
+def secondary_contiger(torch, shk, ctx, text, offs, lens, k):
+    """Contiger (BASELINE config 3) on the filter the timed build has just produced, over the reads of one batch: seeds
+    from the reads, walks on the device, then duplicate removal, numbering, links and the FASTA text."""
+    import tempfile
+    u = shk.UnitigSet(ctx)
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nseeds = 0
+    B = 64
+    for a in range(0, len(offs), B):
+        nseeds += u.add_reads(text.data_ptr(), offs[a:a + B], lens[a:a + B], k, 2, 2, 1000000, 1 << 26, text_bytes=int(text.numel()))
+    torch.cuda.synchronize()
+    t_walk = time.perf_counter() - t0
+    walk_ms = ctx.profile_get().get("k_ug_walk", (0, 0.0))[1]
+    out = os.path.join(tempfile.mkdtemp(), "unitigs.fa")
+    t0 = time.perf_counter()
+    st = u.write(k, out)
+    t_write = time.perf_counter() - t0
+    fin_ms = ctx.profile_get().get("k_ug_check/emit/median/links", (0, 0.0))[1]
+    u.close()
+    try:
+        os.remove(out)
+    except OSError:
+        pass
+    ext = st["extensions"]
+    return {"what": "Contiger -s 2 -x 2 on the filter just built, seeds from one batch of reads (8 M), unitigs.fa written",
+            "seeds": nseeds, "unitigs": st["unitigs"], "total_len": st["total_len"], "walk_wall_s": t_walk,
+            "walk_kernel_s": walk_ms / 1e3, "extended_bases": ext,
+            "bases_per_s_walk_kernel": ext / (walk_ms / 1e3) if walk_ms else None,
+            "lookups_per_s_walk_kernel": 7 * ext / (walk_ms / 1e3) if walk_ms else None,
+            "GBps_at_97B_per_lookup": 97 * 7 * ext / (walk_ms / 1e3) / 1e9 if walk_ms else None,
+            "finish_and_write_s": t_write, "finish_kernels_s": fin_ms / 1e3}
+
+
 def cpu_baseline(torch, text_cpu, offs, lens, k, qb, budget_s=12.0):
     """reference gqf.c + nthash.hpp (oracle/_ref, kind 'reference') or the C restatement (kind 'port') on the
     host cores, over a bounded prefix of the same FASTQ batch: first one thread (the t = 1 path the parity tests
@@ -153,6 +222,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="threads per workgroup (0 = library default)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: SHK_ABLATE bits applied to the timed steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one batch after the other on one stream (shk_count_chunks) instead of the overlapped front end")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (PCIe-inclusive rate, Contiger on the built filter)")
     ap.add_argument("--trace", action="store_true", help="diagnostics: print the filter's counters after every step (adds a sync per step)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/all-to-all code path even with one rank")
     ap.add_argument("--full-build", action="store_true", help="the whole C. elegans-sized build (README.md:90-91: 16.5 G k-mers = 20 steps, no warm-up)")
@@ -207,9 +278,9 @@ def main():
     if args.qb:
         qb = args.qb
 
-    def new_ctx():
+    def new_ctx(host_text_bytes=0):
         return shk.Context(qb=qb, k=K, trigger=(trigger if not sharded else (1 << 62)), num_denoise=(nd if not sharded else 0),
-                           max_batch_bytes=(R * rec + 4096 if args.host_text else 64),
+                           max_batch_bytes=(R * rec + 4096 if args.host_text else max(64, host_text_bytes)),
                            max_batch_keys=int(R * kmers_per_read * (1.5 if sharded else 1.0)) + 4096,
                            max_batch_reads=R + 1024, threads_per_group=args.threads, device=local_rank, shard_index=rank, num_shards=world)
 
@@ -233,6 +304,7 @@ def main():
             self.counted = self.removed = self.rounds = 0
             self.uploaded = {}
             self.inflight = {}
+            self.prepared = set()
 
         def exchange(self, s):
             t = texts[s]
@@ -250,8 +322,20 @@ def main():
                     if s + 1 < nsteps:
                         self.uploaded[s + 1] = ctx.upload_text(texts[s + 1].data_ptr(), texts[s + 1].numel())
                     st = ctx.count_chunks(dptr, offs, lens, on_device=True, text_bytes=t.numel())
-                else:
+                elif args.serial:
                     st = ctx.count_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
+                else:
+                    # overlapped: the front end (parse, hash, partition) of batch s+1 runs on the context's second
+                    # stream while batch s is rebuilt into the table (shk_prepare_chunks / shk_count_prepared)
+                    if s not in self.prepared:
+                        ctx.prepare_chunks(t.data_ptr(), offs, lens, on_device=True, text_bytes=t.numel())
+                        self.prepared.add(s)
+                    if s + 1 < nsteps:
+                        t2 = texts[s + 1]
+                        ctx.prepare_chunks(t2.data_ptr(), offs, lens, on_device=True, text_bytes=t2.numel())
+                        self.prepared.add(s + 1)
+                    st = ctx.count_prepared()
+                    self.prepared.discard(s)
             else:
                 # pipelined: the all-to-all of batch s was started one step ago; before waiting for it, batch s+1 is
                 # hashed, binned by owner (second send buffer) and ITS exchange started -- xGMI moves key words while
@@ -338,7 +422,10 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pk = {"k_region_merge<spill>": "k_region_merge<3, 24, false>", "k_region_merge<fused>": "k_region_merge<3, 24, true>",
                   "k_region_merge<sample>": "k_region_merge<0, 24, false>", "k_region_place": "k_region_place<24>"}.get(name, name)
-            if default_workload and pk in pt["kernels"]:
+            fresh = pt.get("csrc_sha256") == csrc_sha256()     # measured on exactly these kernel sources?
+            if default_workload and not fresh:
+                traffic_src = "stale: profiles/pmc_traffic.json was measured on other kernel sources (csrc_sha256 differs); re-run tools/profile_round.sh"
+            if default_workload and fresh and pk in pt["kernels"]:
                 e = pt["kernels"][pk]
                 traffic = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
                 if pk == "k_region_merge<3, 24, true>":
@@ -346,7 +433,7 @@ def main():
                     # singleton); the HIP events here count the first: bytes per POINT = both
                     traffic *= 2
                 traffic_src = pt["source"]
-            if default_workload:
+            if default_workload and fresh:
                 step_traffic = pt.get("bytes_per_step")
         except (OSError, ValueError, KeyError):
             pass
@@ -383,6 +470,18 @@ def main():
                                 "achieved_real_GBps": (traffic / avg_s / 1e9) if traffic else None},
             "kernel_ms": kern_ms, "kernel_launches": kern_n,
         }
+        if not args.no_secondary and world == 1 and not args.host_text and not args.ablate:
+            # outside the timed region: what the headline value leaves out
+            sec = {}
+            try:
+                sec["contiger"] = secondary_contiger(torch, shk, ctx, texts[0], offs, lens, K)
+            except shk.ShkError as e:
+                sec["contiger"] = {"error": str(e)}
+            try:
+                sec["host_text"] = secondary_host_text(torch, shk, new_ctx, texts, offs, lens)
+            except shk.ShkError as e:
+                sec["host_text"] = {"error": str(e)}
+            out["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             text_cpu = texts[0].cpu().numpy().tobytes()
             out["cpu_baseline"] = cpu_baseline(torch, text_cpu, offs, lens, K, qb)

@@ -112,6 +112,19 @@ int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_
                      const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks,
                      shk_batch_stats *stats);
 
+/* The same in two halves, so that the front end of later batches (parse, hash, partition: its own stream and buffers)
+ * runs WHILE an earlier batch is rebuilt into the table -- the overlapped form of the reference's producer threads
+ * (cqf/CQF_mt.h:821-931 interleaves reading, hashing and inserting across threads). shk_prepare_chunks starts the front
+ * end of a batch and returns at once; shk_count_prepared takes the OLDEST prepared batch through the rebuild (deNoise
+ * rounds fire inside it exactly as in shk_count_chunks) and returns its statistics. At most two batches may be prepared
+ * ahead (SHK_ERR_BATCH beyond). `text` (host or device) must stay valid until the batch has been counted. A failure of
+ * the front end is returned by the shk_count_prepared of that batch; the table is untouched then. Results are those of
+ * shk_count_chunks on the same batches in the same order. Not for sharded contexts (their words go through
+ * shk_hash_chunks and the exchange). */
+int shk_prepare_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
+                       const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks);
+int shk_count_prepared(shk_ctx *ctx, shk_batch_stats *stats);
+
 /* Overlapped ingest: start copying host text (pinned memory for full PCIe rate) for a LATER call into one of two
  * context-owned device buffers; the copy runs on its own stream while the context computes. Pass the returned
  * pointer as `text` with text_on_device = 1; that call waits for the copy. Upload batch s+1, then count batch s. */

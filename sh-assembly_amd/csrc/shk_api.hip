@@ -3,6 +3,7 @@
 // per context; the only host<->device synchronisations in a batch are the one that reads
 // the merge statistics (needed to decide where a deNoise round fires) and the final one.
 #include "../../include/shk.h"
+#include <thread>
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -109,6 +110,7 @@ struct shk_ctx {
   int counted;                  // 1 while shk_insert_counted runs: the words' chunk field is a multiplicity
   uint64_t *d_send[2];          // shk_route_words: two alternating send buffers (allocated on first use), so that the
   int send_next;                // exchange of one batch can run while the next batch is hashed and routed
+  struct ShkFront *front;       // shk_prepare_chunks: the front end (parse, hash, partition) of later batches on its own stream
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libshk: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return SHK_ERR_HIP; } } while (0)
@@ -290,9 +292,11 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   return SHK_OK;
 }
 
+static void front_destroy(shk_ctx *c);
 extern "C" void shk_destroy(shk_ctx *c) {
   if (!c) return;
   hipSetDevice(c->dev);
+  front_destroy(c);
   hipStreamSynchronize(c->stream);
   if (c->copy_stream) {
     hipStreamSynchronize(c->copy_stream);
@@ -435,9 +439,14 @@ static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   { ProfScope ps(c, KP_ROLL_SCATTER);
     const char *nqe = getenv("SHK_ROLL_NQ");            // (measurement: 16-byte quads fetched at a time per stream)
     const int nq = nqe ? atoi(nqe) : 1;
-    if (c->threads >= 512 && getenv("SHK_ROLL_512")) {     // (measurement: 8192-key windows)
+    const char *te = getenv("SHK_ROLL_T");             // (measurement: threads per workgroup = keys per window / 16)
+    const int rt = te ? atoi(te) : 1024;
+    if (c->threads >= 512 && rt == 512) {
       const uint64_t blocks = nreads / 512 + 1;
-      hipLaunchKernelGGL((k_roll_scatter<512, 4>), dim3((uint32_t)(blocks < 1024 ? blocks : 1024)), dim3(512), 0, c->stream, A);
+      hipLaunchKernelGGL((k_roll_scatter<512, 1>), dim3((uint32_t)(blocks < 1024 ? blocks : 1024)), dim3(512), 0, c->stream, A);
+    } else if (c->threads >= 512 && rt == 256) {
+      const uint64_t blocks = nreads / 256 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<256, 1>), dim3((uint32_t)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, c->stream, A);
     } else if (c->threads >= 512) {
       const uint64_t blocks = nreads / 1024 + 1;
       const dim3 grid((uint32_t)(blocks < 512 ? blocks : 512));
@@ -1236,6 +1245,200 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   rc = roll ? partition_stage(c, 0, nwords, &dst, nullptr, false, 1) : partition_stage(c, 0, nwords, &dst, nullptr, true);
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
+  if (stats) *stats = st;
+  return finish(c, rc);
+}
+
+// ------------------------------------------------------------------ overlapped front end
+// shk_count_chunks = front end (parse, hash, partition: bound by HBM and instruction issue in turn) + rebuild (bound by
+// the CUs' LDS pipelines and instruction issue), one after the other on one stream. The two halves of DIFFERENT batches
+// have nothing to do with each other until the rebuild reads the partitioned words, so the front end of batch s+1 can
+// run on a second stream while batch s is rebuilt: shk_prepare_chunks starts it and returns, shk_count_prepared takes
+// the oldest prepared batch through the rebuild. Two batches may be prepared ahead. The front end works in a shadow of the
+// context: its own stream, scalars, error word, scan scratch and partition buffers; two slots of (partitioned words,
+// region bases) alternate between "being prepared" and "being rebuilt". The shadow runs the unchanged stage functions
+// (host synchronisations included) in a helper thread, so the caller's thread is free to drive the rebuild.
+struct ShkFrontSlot {
+  uint64_t *words = nullptr;    // the buffer the last partition level writes into (and the roll kernels, two levels earlier)
+  uint64_t *base = nullptr;     // region bases of that batch
+  std::thread th;
+  bool busy = false;
+  int rc = 0, dst = 0;
+  uint64_t nwords = 0;
+  uint32_t nchunks = 0;
+};
+struct ShkFront {
+  shk_ctx *f = nullptr;
+  ShkFrontSlot slot[2];
+  int head = 0, count = 0;      // oldest prepared slot, prepared slots
+  int par = 0;                  // index of d_words[] the last level writes into
+  uint64_t *scratch = nullptr;  // the other d_words[] of the shadow
+};
+
+static int front_init(shk_ctx *c) {
+  ShkFront *F = new ShkFront();
+  shk_ctx *f = new shk_ctx(*c);
+  F->f = f;
+  f->front = nullptr;
+  f->pending.clear(); f->evpool.clear();
+  f->copy_stream = hipStream_t(); f->d_up[0] = f->d_up[1] = nullptr; f->up_pending[0] = f->up_pending[1] = 0;
+  for (int i = 0; i < KP_N; i++) { f->prof_ms[i] = 0; f->prof_n[i] = 0; }
+  c->front = F;
+  const uint32_t maxch = SHK_MAX_CHUNKS;
+  const uint64_t capk = c->cfg.max_batch_keys;
+  // everything the front end writes is the shadow's own (null first: a failed allocation leaves nothing dangling)
+  f->d_text = nullptr; f->d_chunk_off = f->d_chunk_len = f->d_nlines = f->d_reads_base = f->d_rd_start = f->d_rd_end = nullptr;
+  f->d_rd_chunk = nullptr; f->d_nkeys = nullptr; f->d_key_base = nullptr; f->d_scalars = nullptr; f->d_block_sums = nullptr;
+  f->d_base_sub = nullptr; f->d_cursor = nullptr; f->d_tfb = nullptr; f->d_err = nullptr; f->h_pinned = nullptr;
+  for (int l = 0; l < 4; l++) f->d_hist[l] = nullptr;
+  for (int l = 0; l < 5; l++) f->d_base[l] = nullptr;
+  f->d_words[0] = f->d_words[1] = nullptr;
+  // (a higher stream priority changes nothing measurable: the rebuild's small workgroups refill every CU as fast as they
+  // leave it, whatever the priority of the queue whose big workgroups are waiting)
+  HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  if (dmalloc(&f->d_text, c->cfg.max_batch_bytes + 64)) return SHK_ERR_HIP;
+  if (dmalloc(&f->d_chunk_off, maxch) || dmalloc(&f->d_chunk_len, maxch) || dmalloc(&f->d_nlines, (uint64_t)maxch * SHK_PARSE_SEGS) ||
+      dmalloc(&f->d_reads_base, maxch + 1)) return SHK_ERR_HIP;
+  if (dmalloc(&f->d_rd_start, c->max_reads + 1) || dmalloc(&f->d_rd_end, c->max_reads + 1) || dmalloc(&f->d_nkeys, c->max_reads + 1) ||
+      dmalloc(&f->d_rd_chunk, c->max_reads + 1) || dmalloc(&f->d_key_base, c->max_reads + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&f->d_scalars, 64)) return SHK_ERR_HIP;
+  HIPCHK(hipMemsetAsync(f->d_scalars, 0, 64 * 8, f->stream));
+  { uint64_t mx = capk > c->max_reads ? capk : c->max_reads;
+    uint64_t pw = 1ULL << c->rbits;
+    if (pw > mx) mx = pw;
+    if (dmalloc(&f->d_block_sums, mx / SHK_SCAN_TILE + 4 + 8192)) return SHK_ERR_HIP; }
+  { uint64_t nb = 1;
+    if (dmalloc(&f->d_base[0], 2)) return SHK_ERR_HIP;
+    for (uint32_t l = 0; l < c->nlevels; l++) {
+      const uint64_t n = nb << c->lv[l].bits;
+      if (dmalloc(&f->d_hist[l], (n << c->lv[l].ng_log2) + 1)) return SHK_ERR_HIP;
+      if (l + 1 < c->nlevels && dmalloc(&f->d_base[l + 1], n + 2)) return SHK_ERR_HIP;
+      if (l + 1 == c->nlevels) for (int k2 = 0; k2 < 2; k2++) if (dmalloc(&F->slot[k2].base, n + 2)) return SHK_ERR_HIP;
+      if (l == 0 && dmalloc(&f->d_base_sub, (n << c->lv[0].ng_log2) + 2)) return SHK_ERR_HIP;
+      nb = n;
+    }
+    { const uint64_t first = (1ULL << (c->lv[0].bits + c->lv[0].ng_log2));
+      if (dmalloc(&f->d_cursor, (nb > first ? nb : first) + 2)) return SHK_ERR_HIP; } }
+  if (dmalloc(&f->d_tfb, capk / SHK_RP_TILE + 2)) return SHK_ERR_HIP;
+  if (dmalloc(&f->d_err, 4)) return SHK_ERR_HIP;
+  HIPCHK(hipMemsetAsync(f->d_err, 0, 16, f->stream));
+  HIPCHK(hipHostMalloc((void **)&f->h_pinned, 64 * sizeof(uint64_t), hipHostMallocDefault));
+  // the roll kernels write d_words[0]; every further level flips: the last one lands in d_words[(nlevels - 1) & 1]
+  F->par = roll_path(c) ? (int)((c->nlevels - 1) & 1) : (int)(c->nlevels & 1);
+  if (dmalloc(&F->scratch, capk + 1) || dmalloc(&F->slot[0].words, capk + 1) || dmalloc(&F->slot[1].words, capk + 1)) return SHK_ERR_HIP;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return SHK_OK;
+}
+static void front_destroy(shk_ctx *c) {
+  ShkFront *F = c->front;
+  if (!F) return;
+  for (int k2 = 0; k2 < 2; k2++) if (F->slot[k2].th.joinable()) F->slot[k2].th.join();
+  shk_ctx *f = F->f;
+  if (f) {
+    if (f->stream) hipStreamSynchronize(f->stream);
+    prof_collect(f);
+    for (size_t i = 0; i < f->evpool.size(); i++) hipEventDestroy(f->evpool[i]);
+    hipFree(f->d_text); hipFree(f->d_chunk_off); hipFree(f->d_chunk_len); hipFree(f->d_nlines); hipFree(f->d_reads_base);
+    hipFree(f->d_rd_start); hipFree(f->d_rd_end); hipFree(f->d_rd_chunk); hipFree(f->d_nkeys); hipFree(f->d_key_base); hipFree(f->d_scalars);
+    hipFree(f->d_block_sums); hipFree(f->d_base[0]); hipFree(f->d_base_sub);
+    for (uint32_t l = 0; l < c->nlevels; l++) { hipFree(f->d_hist[l]); if (l + 1 < c->nlevels) hipFree(f->d_base[l + 1]); }
+    hipFree(f->d_cursor); hipFree(f->d_tfb); hipFree(f->d_err);
+    if (f->h_pinned) hipHostFree(f->h_pinned);
+    if (f->stream) hipStreamDestroy(f->stream);
+    delete f;
+  }
+  hipFree(F->scratch);
+  for (int k2 = 0; k2 < 2; k2++) { hipFree(F->slot[k2].words); hipFree(F->slot[k2].base); }
+  delete F;
+  c->front = nullptr;
+}
+
+// the front end of one batch in the shadow context; runs in the helper thread
+static void front_run(shk_ctx *c, ShkFrontSlot *S, const void *text, int on_device, uint64_t text_bytes, std::vector<uint64_t> off,
+                      std::vector<uint64_t> len) {
+  ShkFront *F = c->front;
+  shk_ctx *f = F->f;
+  hipSetDevice(c->dev);
+  f->prof_on = c->prof_on;
+  f->d_words[F->par] = S->words; f->d_words[F->par ^ 1] = F->scratch;
+  f->d_base[c->nlevels] = S->base;
+  const uint32_t nchunks = (uint32_t)off.size();
+  const bool roll = roll_path(c);
+  S->nwords = 0; S->nchunks = nchunks;
+  int rc = roll ? roll_stage(f, text, on_device, text_bytes, off.data(), len.data(), nchunks, 0, 1)
+                : hash_stage(f, text, on_device, text_bytes, off.data(), len.data(), nchunks, 0, 1, true);
+  uint32_t bits = 0;
+  if (!rc) {
+    if (hipMemcpyAsync(f->h_pinned + 42, f->d_scalars + 1, 8, hipMemcpyDeviceToHost, f->stream) != hipSuccess || fetch_err(f, &bits)) rc = SHK_ERR_HIP;
+    else if (bits) rc = map_err_bits(bits);
+    else if (f->h_pinned[42] > c->cfg.max_batch_keys) rc = SHK_ERR_BATCH;
+  }
+  if (!rc) {
+    S->nwords = f->h_pinned[42];
+    int dst = 0;
+    rc = roll ? partition_stage(f, 0, S->nwords, &dst, nullptr, false, 1) : partition_stage(f, 0, S->nwords, &dst, nullptr, true);
+    S->dst = dst;
+    if (!rc) {
+      if (fetch_err(f, &bits)) rc = SHK_ERR_HIP;          // (synchronises the shadow's stream: the batch is ready)
+      else if (bits) rc = map_err_bits(bits);
+      else if (dst != F->par) rc = SHK_ERR_CORRUPT;       // (the slot's buffer must be the one the last level wrote)
+    }
+  }
+  if (rc) hipStreamSynchronize(f->stream);
+  S->rc = rc;
+}
+
+extern "C" int shk_prepare_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                                  const uint64_t *chunk_len, uint32_t nchunks) {
+  if (!c || !text || !chunk_off || !chunk_len || nchunks == 0 || nchunks > SHK_MAX_CHUNKS) return SHK_ERR_ARG;
+  if (c->cfg.num_shards > 1) return SHK_ERR_ARG;          // (a shard's words go through the exchange: shk_hash_chunks)
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->front) { int rc = front_init(c); if (rc) { front_destroy(c); return rc; } }
+  ShkFront *F = c->front;
+  if (F->count == 2) return SHK_ERR_BATCH;                // two batches are prepared already: count one first
+  ShkFrontSlot *S = &F->slot[(F->head + F->count) & 1];
+  // one front end at a time: the previous one (the other slot's) must have left the shadow's buffers
+  ShkFrontSlot *O = &F->slot[(F->head + F->count + 1) & 1];
+  if (O->th.joinable()) O->th.join();
+  if (text_on_device)
+    for (int b = 0; b < 2; b++)   // a buffer of shk_upload_text whose copy may still be running
+      if (c->d_up[b] && text == (const void *)c->d_up[b] && c->up_pending[b]) { HIPCHK(hipStreamWaitEvent(F->f->stream, c->up_done[b], 0)); c->up_pending[b] = 0; }
+  std::vector<uint64_t> off(chunk_off, chunk_off + nchunks), len(chunk_len, chunk_len + nchunks);
+  S->busy = true;
+  F->count++;
+#if defined(__HIPCC__)
+  S->th = std::thread(front_run, c, S, text, text_on_device, text_bytes, std::move(off), std::move(len));
+#else     // (the CPU emulator build of the tests keeps its kernels on the calling thread)
+  front_run(c, S, text, text_on_device, text_bytes, std::move(off), std::move(len));
+#endif
+  return SHK_OK;
+}
+
+extern "C" int shk_count_prepared(shk_ctx *c, shk_batch_stats *stats) {
+  if (!c || !c->front || c->front->count == 0) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  ShkFront *F = c->front;
+  ShkFrontSlot *S = &F->slot[F->head];
+  if (S->th.joinable()) S->th.join();
+  F->head ^= 1; F->count--;
+  S->busy = false;
+  shk_ctx *f = F->f;
+  shk_batch_stats st;
+  memset(&st, 0, sizeof(st));
+  if (stats) *stats = st;
+  // the front end's kernel times join the context's (its events were recorded on the shadow's stream)
+  { // (the other slot's front end may be running: it only appends to f->pending from its own thread, so collect
+    // what THIS batch left only when nobody else is inside the shadow)
+    ShkFrontSlot *O = &F->slot[F->head];
+    if (!(O->busy && O->th.joinable())) {
+      prof_collect(f);
+      for (int i = 0; i < KP_N; i++) { c->prof_ms[i] += f->prof_ms[i]; c->prof_n[i] += f->prof_n[i]; f->prof_ms[i] = 0; f->prof_n[i] = 0; }
+    } }
+  if (S->rc) return S->rc;
+  uint64_t *saved = c->d_base[c->nlevels];
+  c->d_base[c->nlevels] = S->base;
+  int rc = merge_stage(c, S->words, S->nchunks, S->nwords, &st);
+  c->d_base[c->nlevels] = saved;
   if (stats) *stats = st;
   return finish(c, rc);
 }

@@ -1056,3 +1056,35 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert cb["kind"] == "reference" and cb["unit"] == "k-mers/s" and cb["cores"] >= 1 and cb["value"] > 1e6 and cb["sample"]
     # every k-mer of the build was counted: steps x reads x (L - k + 1), minus the reads' N restarts
     assert d["build_kmers"] > 0.99 * 3 * 8_000_000 * 104
+
+
+def test_overlapped_front_end_matches_oracle():
+    """shk_prepare_chunks / shk_count_prepared: the front end of batch s+1 (helper thread, second stream, shadow buffers)
+    runs while batch s is rebuilt; table, header, counters, rounds and removed counts equal the oracle's t = 1 build --
+    two batches prepared ahead, deNoise rounds inside, and the same chunks through shk_count_chunks give the same bytes"""
+    qb, k, trig, nd, ml = 19, 47, 60000, 4, 1 << 11
+    fq = synth.make_fastq(synth.make_genome(30000, 5), 4200, 150, 0.01, seed=9, n_frac=0.05, short_frac=0.02, lower_frac=0.02)
+    offs, lens = chunks_by_records(fq, 150)
+    q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, trig, nd, False, ml)
+    assert not q.full() and orounds >= 2
+    ctx = _ctx(qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=len(fq) + 1024, max_batch_keys=4200 * 150)
+    nb = 7
+    per = (len(offs) + nb - 1) // nb
+    parts = [(a, min(a + per, len(offs))) for a in range(0, len(offs), per)]
+    rounds = removed = 0
+    ctx.prepare_chunks(fq, offs[parts[0][0]:parts[0][1]], lens[parts[0][0]:parts[0][1]])
+    for i in range(len(parts)):
+        if i + 1 < len(parts):
+            a, b = parts[i + 1]
+            ctx.prepare_chunks(fq, offs[a:b], lens[a:b])          # two batches are prepared ahead at this moment
+        st = ctx.count_prepared()
+        rounds += st["denoise_rounds"]
+        removed += st["removed"]
+    t = ctx.totals()
+    assert (rounds, removed) == (orounds, oremoved) and (t.nelts, t.ndistinct) == (q.nelts(), q.ndistinct())
+    assert ctx.blocks() == q.blocks() and ctx.header() == oracle_header(q)
+    import shk
+    with pytest.raises(shk.ShkError):
+        ctx.count_prepared()                                      # nothing is prepared
+    ctx.close()
+    q.free()

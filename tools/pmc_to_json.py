@@ -21,7 +21,9 @@ def main():
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)", line)
         if m and cur is not None:
             cur[m.group(1)] += float(m.group(2))
-    out = {"workload": "bench.py --steps %d --warmup 0 (8,000,000 reads/step, qb 29: the whole build with its deNoise points)" % steps,
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+    import bench
+    out = {"csrc_sha256": bench.csrc_sha256(), "workload": "bench.py --steps %d --warmup 0 (8,000,000 reads/step, qb 29: the whole build with its deNoise points)" % steps,
            "source": source, "units": "bytes; FETCH_SIZE (KiB) x 1024 x 2 (gfx950 correction), WRITE_SIZE (KiB) x 1024", "kernels": {}}
     total = 0.0
     for name, v in kernels.items():
