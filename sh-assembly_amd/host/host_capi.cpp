@@ -2,6 +2,7 @@
 // check them against the oracle without a GPU (libshkhost.so, built with g++).
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,40 @@ int shkh_stitch(const uint8_t *const *shards, const uint64_t *shard_blocks, uint
                 uint64_t out_bytes) {
   return shk::stitch_shards(shards, shard_blocks, nshards, qb, out, out_bytes);
 }
+// the stitch, one rank at a time (stitch.hpp). shkh_shard_layout returns the number of spilled slots (or < 0); the spill
+// itself is fetched with shkh_shard_spill afterwards (kept in a thread-local buffer in between)
+int shkh_shard_summary(const uint8_t *shard, uint64_t shard_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t *ab) {
+  return shk::shard_summary(shard, shard_blocks, g, nshards, qb, ab, ab + 1);
+}
+static thread_local std::vector<uint8_t> t_spill_slots, t_spill_runends;
+long long shkh_shard_layout(const uint8_t *shard, uint64_t shard_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t free_in,
+                            uint8_t *own_blocks, uint64_t own_bytes, uint64_t *spill_start, uint64_t *free_out) {
+  int rc = shk::shard_layout(shard, shard_blocks, g, nshards, qb, free_in, own_blocks, own_bytes, &t_spill_slots, &t_spill_runends,
+                             spill_start, free_out);
+  return rc ? rc : (long long)t_spill_slots.size();
+}
+void shkh_shard_spill(uint8_t *slots, uint8_t *runends) {
+  if (!t_spill_slots.empty()) { memcpy(slots, t_spill_slots.data(), t_spill_slots.size()); memcpy(runends, t_spill_runends.data(), t_spill_runends.size()); }
+}
+int shkh_shard_apply_spill(uint8_t *own_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t spill_start, const uint8_t *slots,
+                           const uint8_t *runends, uint64_t n) {
+  return shk::shard_apply_spill(own_blocks, g, nshards, qb, spill_start, slots, runends, n);
+}
+// the chunker as an iterator (the multi-GPU launcher shk/count.py reads its parts through this)
+void *shkh_batch_open(const char **paths, int nfiles, int mode, uint64_t part_size, uint32_t overhead) {
+  std::vector<std::string> f(paths, paths + nfiles);
+  return new shk::seqFile_batch(f, shk::FASTQ, mode == 1 ? shk::GZIP : mode == 2 ? shk::BZIP2 : shk::TEXT, part_size, overhead);
+}
+// 1 = a part (malloc'ed: shkh_free it), 0 = end, -1 = error (wrong input file)
+int shkh_batch_next(void *h, char **data, uint64_t *size) {
+  shk::seqFile_batch *b = (shk::seqFile_batch *)h;
+  shk::chunk c;
+  if (b->getDataChunk(c)) { *data = c.get_reads(); *size = c.get_size(); return 1; }
+  return b->bad() ? -1 : 0;
+}
+int shkh_batch_files(void *h) { return ((shk::seqFile_batch *)h)->num_files(); }
+void shkh_free(void *p) { free(p); }
+void shkh_batch_close(void *h) { delete (shk::seqFile_batch *)h; }
 // alpha = -1: the true:false ratio comes from the error profile file
 void shkh_size_filter_profile(int K, uint64_t n_true, uint64_t N_total, const char *profile, int num_denoise, double fr, uint64_t *out) {
   shk::Sizing s = shk::size_filter(K, n_true, N_total, -1, profile, num_denoise, fr);

@@ -19,4 +19,14 @@ namespace shk {
 int stitch_shards(const uint8_t *const *shards, const uint64_t *shard_blocks, uint32_t nshards, uint32_t qb,
                   uint8_t *out, uint64_t out_bytes);
 
+// The same layout, rank by rank (no rank sees another's table; see stitch.cpp): the shard as a free-pointer function
+// f -> max(f + a, b); the rank's own blocks of the single table for the free pointer it starts from, plus what its runs
+// spill behind its block range; a received spill ORed into the rank's blocks.
+int shard_summary(const uint8_t *shard, uint64_t shard_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t *a, uint64_t *b);
+int shard_layout(const uint8_t *shard, uint64_t shard_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t free_in,
+                 uint8_t *own_blocks, uint64_t own_bytes, std::vector<uint8_t> *spill_slots, std::vector<uint8_t> *spill_runends,
+                 uint64_t *spill_start, uint64_t *free_out);
+int shard_apply_spill(uint8_t *own_blocks, uint32_t g, uint32_t nshards, uint32_t qb, uint64_t spill_start, const uint8_t *slots,
+                      const uint8_t *runends, uint64_t n);
+
 }  // namespace shk

@@ -597,27 +597,111 @@ def route_words(ctx, nwords, hb, world, rank, device):
     return Exchange(ctx, nwords, hb, world, rank, device, async_op=False).wait()
 
 
+_HOSTLIB = None
+
+
+def _hostlib():
+    """libshkhost.so: the host-only pieces (chunker, per-rank stitch)"""
+    global _HOSTLIB
+    if _HOSTLIB is None:
+        import ctypes as C
+        L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libshkhost.so"))
+        L.shkh_shard_summary.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.shkh_shard_layout.restype = C.c_longlong
+        L.shkh_shard_layout.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64,
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.shkh_shard_spill.argtypes = [C.c_char_p, C.c_char_p]
+        L.shkh_shard_apply_spill.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint64]
+        _HOSTLIB = L
+    return _HOSTLIB
+
+
+def cqf_header(qb, seed, nelts, ndistinct):
+    """the 128-byte qfmetadata image qf_serialize writes (cqf/gqf.h:62-77, cqf/CQF_mt.h:986-987) for the WHOLE filter"""
+    import math
+    import struct
+    nslots = 1 << qb
+    xnslots = nslots + int(10 * math.sqrt(float(nslots)))
+    nblocks = (xnslots + 63) // 64
+    h = bytearray(128)
+    struct.pack_into("<Q", h, 0, nblocks * 89)
+    struct.pack_into("<I", h, 8, seed)
+    struct.pack_into("<QQQQQQ", h, 16, nslots, xnslots, qb + 8, 0, 8, 8)
+    h[64:80] = (nslots << 8).to_bytes(16, "little")
+    struct.pack_into("<QQQQQ", h, 80, nblocks, nelts, ndistinct, 0, xnslots // (1 << 16) + 2)
+    return bytes(h)
+
+
 def export_cqf(ctx, st, path, world, rank, device, qb, k=21):
-    """One .cqf of the whole filter from the ranks' shards: rank 0 gathers the shard tables (device to device over
-    RCCL / gloo), re-lays their runs into the single table on its GPU (shk_import_shards: clusters may now cross the
-    old shard borders) and writes header + blocks exactly as qf_serialize would. Returns the path on rank 0."""
-    from . import Context
-    ptr, nbytes = ctx.table_ptr()
-    mine = torch.empty((nbytes + 16,), dtype=torch.uint8, device=device)
-    mine[:nbytes].copy_(wrap_bytes(ptr, nbytes, device))
-    mine[nbytes:].zero_()
-    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-    if world > 1:
-        dist.gather(mine, parts, dst=0)
-    else:
-        parts = [mine]
-    if rank != 0:
-        return None
-    full = Context(qb=qb, k=k, max_batch_keys=1 << 16, device=(device.index or 0) if device.type == "cuda" else 0,
-                   lib_path=getattr(ctx, "lib_path", None))
+    """One .cqf of the whole filter written BY ALL RANKS, each placing its own blocks (qf_serialize's bytes,
+    cqf/gqf.c:2379-2394): nobody gathers anybody's table. A shard is a function on the free pointer, f -> max(f + a, b)
+    (a = slots its runs take, b = where they end with nothing carried in): the ranks all-gather their (a, b), fold the
+    pairs of the ranks in front of them into the free pointer they start from, lay their runs out into their own block
+    range of the single table (host/stitch.cpp: occupieds, runends, slots, block offsets) and exchange what spills
+    behind it -- normally a few hundred slots. Rank 0 writes the header; every rank pwrites its blocks at their
+    offset. Returns the path on every rank."""
+    import ctypes as C
+    import math
+    L = _hostlib()
+    nslots = 1 << qb
+    xnslots = nslots + int(10 * math.sqrt(float(nslots)))
+    nblocks = (xnslots + 63) // 64
+    per = nslots // world
+    shard = ctx.blocks()                                   # this shard's table, device -> host
+    ab = (C.c_uint64 * 2)()
+    rc = L.shkh_shard_summary(shard, len(shard) // 89, rank, world, qb, ab)
+    # the pair, the local return code and (later) the spill's start and length travel in all-gathers: a rank whose
+    # shard is damaged still takes part, and every rank raises
+    mine = torch.tensor([int(ab[0]), int(ab[1]), rc], dtype=torch.int64, device=device)
+    allv = torch.empty((world * 3,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allv, mine)
+    allv = allv.view(world, 3).tolist()
+    if any(v[2] for v in allv):
+        raise ShkError(-5, "a shard's table is inconsistent (rank %d)" % next(p for p in range(world) if allv[p][2]))
+    free_in = 0
+    for p in range(rank):
+        free_in = max(free_in + allv[p][0], allv[p][1])
+    b_lo = per * rank // 64
+    b_hi = nblocks if rank == world - 1 else per * (rank + 1) // 64
+    own = C.create_string_buffer((b_hi - b_lo) * 89)
+    ss, fo = C.c_uint64(), C.c_uint64()
+    n = L.shkh_shard_layout(shard, len(shard) // 89, rank, world, qb, free_in, own, len(own), C.byref(ss), C.byref(fo))
+    del shard
+    sl, re_ = C.create_string_buffer(max(int(n), 1)), C.create_string_buffer(max(int(n), 0) // 8 + 1)
+    if n > 0:
+        L.shkh_shard_spill(sl, re_)
+    mine = torch.tensor([int(ss.value), int(n)], dtype=torch.int64, device=device)
+    alls = torch.empty((world * 2,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(alls, mine)
+    alls = alls.view(world, 2).tolist()
+    if any(v[1] < 0 for v in alls):
+        raise ShkError(-3, "the stitched runs pass the end of the table (rank %d)" % next(p for p in range(world) if alls[p][1] < 0))
+    mx = max(v[1] for v in alls)
+    if mx > 0:
+        # spills: slot bytes, then the run-end bits, padded to the longest
+        width = mx + mx // 8 + 1
+        blob = torch.zeros((width,), dtype=torch.uint8)
+        if n > 0:
+            blob[:n] = torch.frombuffer(bytearray(sl.raw[:n]), dtype=torch.uint8)
+            blob[mx:mx + n // 8 + 1] = torch.frombuffer(bytearray(re_.raw[:n // 8 + 1]), dtype=torch.uint8)
+        blob = blob.to(device)
+        allb = torch.empty((world * width,), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(allb, blob)
+        allb = allb.view(world, width).cpu()
+        for p in range(rank):                              # whatever earlier ranks spill may land in my blocks
+            sp, np_ = alls[p]
+            if np_ > 0 and sp + np_ > b_lo * 64:
+                row = allb[p].numpy().tobytes()
+                L.shkh_shard_apply_spill(own, rank, world, qb, sp, row[:np_], row[mx:mx + np_ // 8 + 1], np_)
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.write(cqf_header(qb, ctx.cfg.seed, st.nelts, st.ndistinct))
+            f.truncate(128 + nblocks * 89)
+    dist.barrier()
+    fd = os.open(path, os.O_WRONLY)
     try:
-        full.import_shards_device([p.data_ptr() for p in parts], nbytes, st.nelts, st.ndistinct)
-        full.export_cqf(path)
+        os.pwrite(fd, own.raw, 128 + b_lo * 89)
     finally:
-        full.close()
+        os.close(fd)
+    dist.barrier()
     return path

@@ -39,6 +39,21 @@ def build_blocks(qb, hb, counts):
     """counts: dict key->count (key < 2^hb, hb == qb+8). returns bytes of nblocks*89"""
     assert hb == qb + 8
     nslots, xnslots, nblocks = geometry(qb, hb)
+    return build_blocks_geom(xnslots, counts)
+
+
+def build_shard_blocks(qb, g, nshards, counts):
+    """the table of quotient-range shard g of `nshards` (keys with quotient in [g, g+1) * 2^qb / nshards, stored with
+    quotients relative to the shard's first one; its own overflow tail of 10 * sqrt(2^qb) slots, as libshk lays shards out)"""
+    nslots = 1 << qb
+    per = nslots // nshards
+    q_lo = per * g
+    local = {k - (q_lo << 8): c for k, c in counts.items() if q_lo <= (k >> 8) < q_lo + per}
+    return build_blocks_geom(per + int(10 * math.sqrt(float(nslots))), local)
+
+
+def build_blocks_geom(xnslots, counts):
+    nblocks = (xnslots + 63) // 64
     slots = np.zeros(nblocks * 64, dtype=np.uint8)
     occ = np.zeros(nblocks * 64, dtype=np.uint8)
     rend = np.zeros(nblocks * 64, dtype=np.uint8)

@@ -202,3 +202,39 @@ def test_a_rank_local_failure_in_front_of_the_exchange_is_raised_on_every_rank()
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] is not None and res[0][1] == res[1][1] and res[0][1] < 0, res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_gpu_front_end_reproduces_the_golden_cqf_files(world, tmp_path):
+    """python -m shk.count, the multi-GPU CQF-deNoise (parts round-robin over the ranks, all-to-all, collective rebuild and
+    deNoise rounds, every rank pwriting its own blocks of the .cqf), on the golden FASTQ files with 2 and 4 gloo ranks on
+    the emulator build: the files the REFERENCE build wrote (tests/golden/build0..3.cqf) come out byte for byte -- without
+    rounds, with 3 rounds, and with 6 rounds + --endDeNoise at a range length of 1024 slots"""
+    import json
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sh-assembly_amd"), os.path.join(ROOT, "sh-assembly_amd", "libshkhost.so")])
+    G = os.path.join(ROOT, "tests", "golden")
+    fx = json.load(open(os.path.join(G, "fastq_builds.json")))
+    done = 0
+    for bi, b in enumerate(fx["builds"][:4]):
+        c = b["cfg"]
+        if (1 << c["qb"]) // world < 256:
+            continue
+        lst = tmp_path / ("files%d.txt" % bi)
+        lst.write_text("\n".join(os.path.join(G, f) for f in c["files"]) + "\n")     # (absolute names: the prefix rule leaves them alone)
+        out = str(tmp_path / ("out%d.cqf" % bi))
+        args = ["-k", str(c["k"]), "-n", "6000", "-N", "100000", "-e", "0.01", "-f", "f", "-i", str(lst), "-o", out,
+                "--deNoise", str(c["nd"]), "--rounds", str(c["nd"]), "--qb", str(c["qb"]), "--trigger", str(min(c["trigger"], 1 << 62)),
+                "--part-size", str(c["ps"]), "--overhead", str(c["ov"]), "--min-denoise-len", str(c["ml"]),
+                "--parts-per-call", "2", "--backend", "gloo", "--lib", EMU]
+        if c["end"]:
+            args.append("--endDeNoise")
+        port = 29600 + (os.getpid() * 7 + world * 13 + bi) % 300
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "sh-assembly_amd"), SHK_SAMPLE_STRIDE="2")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "shk.count"] + args,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert open(out, "rb").read() == open(os.path.join(G, b["cqf"]), "rb").read(), (c, r.stderr[-600:])
+        done += 1
+    assert done >= 3

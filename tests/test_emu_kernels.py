@@ -496,3 +496,30 @@ def test_randomised_configurations_on_the_emulator(shk, flow):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert "12 cases, 0 mismatches" in r.stdout
+
+
+def test_prepared_batches_give_the_same_filter(shk):
+    """shk_prepare_chunks / shk_count_prepared (on the emulator the front end runs on the calling thread; the GPU suite
+    runs it on its helper thread and second stream): shadow buffers, two alternating slots, two batches prepared ahead,
+    deNoise rounds inside -- same table, header, rounds and removed counts as the oracle's t = 1 build"""
+    fq = synth.make_fastq(synth.make_genome(800, 1), 90, 100, 0.01, seed=3, n_frac=0.25, short_frac=0.1, lower_frac=0.05)
+    offs, lens = chunks_by_records(fq, 10)
+    k, qb, trig, nd, ml = 47, 12, 2500, 3, 64
+    ctx = _ctx(shk, qb=qb, k=k, trigger=trig, num_denoise=nd, min_denoise_len=ml, max_batch_bytes=1 << 20, max_batch_keys=1 << 16,
+               max_level_bits=2)
+    third = len(offs) // 3
+    parts = [(0, third), (third, 2 * third), (2 * third, len(offs))]
+    rounds = removed = 0
+    ctx.prepare_chunks(fq, offs[:third], lens[:third])
+    for i in range(3):
+        if i + 1 < 3:
+            a, b = parts[i + 1]
+            ctx.prepare_chunks(fq, offs[a:b], lens[a:b])
+        st = ctx.count_prepared()
+        rounds += st["denoise_rounds"]
+        removed += st["removed"]
+    q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, trig, nd, False, ml)
+    assert orounds >= 1 and (rounds, removed) == (orounds, oremoved)
+    assert ctx.blocks() == q.blocks() and ctx.header() == oracle_header(q)
+    ctx.close()
+    q.free()

@@ -1088,3 +1088,30 @@ def test_overlapped_front_end_matches_oracle():
         ctx.count_prepared()                                      # nothing is prepared
     ctx.close()
     q.free()
+
+
+def test_multi_gpu_front_end_one_rank_over_rccl(tmp_path):
+    """python -m shk.count (the multi-GPU CQF-deNoise: parts round-robin, all-to-all, collective rebuild, every rank
+    pwriting its blocks) with ONE rank over RCCL on the real kernels: the golden .cqf files come out byte for byte.
+    (2 and 4 ranks run over gloo on the emulator in tests/test_dist_gloo.py; more GPUs are the driver's to launch.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = os.path.join(root, "tests", "golden")
+    fx = json.load(open(os.path.join(G, "fastq_builds.json")))
+    for bi, b in enumerate(fx["builds"][:4]):
+        c = b["cfg"]
+        lst = tmp_path / ("files%d.txt" % bi)
+        lst.write_text("\n".join(os.path.join(G, f) for f in c["files"]) + "\n")
+        out = str(tmp_path / ("out%d.cqf" % bi))
+        args = ["-k", str(c["k"]), "-n", "6000", "-N", "100000", "-e", "0.01", "-f", "f", "-i", str(lst), "-o", out,
+                "--deNoise", str(c["nd"]), "--rounds", str(c["nd"]), "--qb", str(c["qb"]), "--trigger", str(min(c["trigger"], 1 << 62)),
+                "--part-size", str(c["ps"]), "--overhead", str(c["ov"]), "--min-denoise-len", str(c["ml"]), "--parts-per-call", "3"]
+        if c["end"]:
+            args.append("--endDeNoise")
+        env = dict(os.environ, PYTHONPATH=os.path.join(root, "sh-assembly_amd"), SHK_SAMPLE_STRIDE="2")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", str(29650 + bi), "-m", "shk.count"] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert open(out, "rb").read() == open(os.path.join(G, b["cqf"]), "rb").read(), (c, r.stderr[-600:])

@@ -260,3 +260,70 @@ def test_chunker_fails_on_damaged_streams_and_tiny_parts(tmp_path):
     buf = rec * 12
     cutpos = L.shkh_record_cut(buf, len(buf), 65535)                           # n < overhead / 2
     assert cutpos and cutpos % len(rec) == 0
+
+
+def test_stitch_rank_by_rank_equals_the_single_table():
+    """host/stitch.cpp, the per-rank form behind the distributed export (shk.dist.export_cqf): every rank summarises its
+    shard as f -> max(f + a, b), folds the pairs of the ranks in front of it into its incoming free pointer, lays out ITS
+    OWN blocks of the single table and hands on what spills behind them. Concatenated, the ranks' blocks are the single
+    table byte for byte -- with clusters that cross one seam, several seams (a shard of 256 quotients under a 700-slot
+    cluster), and the overflow tail."""
+    import ctypes as C
+    import random
+    from cqf_canon import build_blocks, build_shard_blocks, geometry
+    L = _hostlib()
+    L.shkh_shard_summary.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.shkh_shard_layout.restype = C.c_longlong
+    L.shkh_shard_layout.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.shkh_shard_spill.argtypes = [C.c_char_p, C.c_char_p]
+    L.shkh_shard_apply_spill.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint64]
+    rnd = random.Random(12)
+    done = multi = 0
+    for trial in range(40):
+        qb = rnd.choice([11, 12, 13])
+        G = rnd.choice([2, 4, 8])
+        nslots, xnslots, nblocks = geometry(qb, qb + 8)
+        per = nslots // G
+        counts = {}
+        for _ in range(rnd.choice([200, 600])):
+            counts[(rnd.randrange(nslots) << 8) | rnd.randrange(256)] = rnd.choice([1, 1, 2, 3, 200, 20000])
+        for _ in range(rnd.choice([1, 2, 3])):                       # dense clusters right in front of seams / the end
+            seam = rnd.randrange(1, G + 1) * per
+            base = max(0, seam - rnd.choice([10, 60, 200]))
+            for _ in range(rnd.choice([150, 300, 420])):
+                counts[((base + rnd.randrange(0, 40)) % nslots) << 8 | rnd.randrange(256)] = rnd.choice([1, 2, 300])
+        try:
+            want = build_blocks(qb, qb + 8, counts)
+            shards = [build_shard_blocks(qb, g, G, counts) for g in range(G)]
+        except OverflowError:                                        # (a cluster longer than a shard's own tail)
+            continue
+        done += 1
+        ab = []
+        for g in range(G):
+            v = (C.c_uint64 * 2)()
+            assert L.shkh_shard_summary(shards[g], len(shards[g]) // 89, g, G, qb, v) == 0
+            ab.append((v[0], v[1]))
+        F = [0]
+        for a, b in ab:
+            F.append(max(F[-1] + a, b))
+        own, spills = [], []
+        for g in range(G):
+            b_lo = per * g // 64
+            b_hi = nblocks if g == G - 1 else per * (g + 1) // 64
+            buf = C.create_string_buffer((b_hi - b_lo) * 89)
+            ss, fo = C.c_uint64(), C.c_uint64()
+            n = L.shkh_shard_layout(shards[g], len(shards[g]) // 89, g, G, qb, F[g], buf, len(buf), C.byref(ss), C.byref(fo))
+            assert n >= 0 and fo.value == F[g + 1]
+            sl, re_ = C.create_string_buffer(max(n, 1)), C.create_string_buffer(n // 8 + 1)
+            L.shkh_shard_spill(sl, re_)
+            own.append(buf)
+            spills.append((ss.value, n, sl, re_))
+        for g in range(G):
+            for h in range(g):                                       # every earlier rank's spill may reach this one
+                ss, n, sl, re_ = spills[h]
+                if n:
+                    L.shkh_shard_apply_spill(own[g], g, G, qb, ss, sl, re_, n)
+        assert b"".join(o.raw for o in own) == want, (trial, qb, G)
+        multi += sum(1 for g in range(G - 1) if spills[g][1] > per)
+    assert done >= 15 and multi >= 1                                  # some spill passed over a whole shard
