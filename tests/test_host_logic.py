@@ -3,6 +3,8 @@ import importlib.util
 import os
 import sys
 
+import pytest
+
 import cqflibs
 import synth
 
@@ -327,3 +329,140 @@ def test_stitch_rank_by_rank_equals_the_single_table():
         assert b"".join(o.raw for o in own) == want, (trial, qb, G)
         multi += sum(1 for g in range(G - 1) if spills[g][1] > per)
     assert done >= 15 and multi >= 1                                  # some spill passed over a whole shard
+
+
+class _CompatQF:
+    """ctypes view of include/gqf_compat.h (libshkhost.so): the gqf-named per-key host API"""
+
+    def __init__(self, L, qb=None, path=None):
+        import ctypes as C
+        self.L, self.C = L, C
+
+        class QF(C.Structure):
+            _fields_ = [("mem", C.c_void_p), ("metadata", C.c_void_p), ("blocks", C.c_void_p)]
+
+        class QFi(C.Structure):
+            _fields_ = [("qf", C.c_void_p), ("run", C.c_uint64), ("current", C.c_uint64), ("cur_start_index", C.c_uint64),
+                        ("cur_length", C.c_uint16), ("num_clusters", C.c_uint32), ("c_info", C.c_void_p)]
+        self.QFi = QFi
+        self.qf = QF()
+        u64, vp = C.c_uint64, C.c_void_p
+        L.qf_init.argtypes = [vp, u64, u64, u64, C.c_bool, C.c_char_p, C.c_uint32]
+        L.qf_destroy.argtypes = [vp, C.c_bool]
+        L.qf_insert_advance.restype = C.c_bool
+        L.qf_insert_advance.argtypes = [vp, u64, u64, u64, C.c_bool, C.c_bool, C.POINTER(C.c_bool)]
+        L.qf_count_key_value.restype = u64
+        L.qf_count_key_value.argtypes = [vp, u64, u64]
+        for n in ("qf_count_key_value_set_traveled", "qf_count_key_value_is_traveled"):
+            getattr(L, n).restype = C.c_bool
+            getattr(L, n).argtypes = [vp, u64, u64, C.POINTER(u64)]
+        for n in ("find_first_empty_slot", "find_first_nonempty_slot"):
+            getattr(L, n).restype = u64
+            getattr(L, n).argtypes = [vp, u64]
+        L.qf_clean_singleton.argtypes = [vp, u64, u64, C.POINTER(u64)]
+        L.check_offset.restype = C.c_bool
+        L.check_offset.argtypes = [vp]
+        L.popcnt_occupieds.restype = L.popcnt_runends.restype = u64
+        L.popcnt_occupieds.argtypes = L.popcnt_runends.argtypes = [vp]
+        L.qf_iterator.restype = C.c_bool
+        L.qf_iterator.argtypes = [vp, vp, u64]
+        L.qfi_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.qfi_next.argtypes = L.qfi_end.argtypes = [vp]
+        L.qf_serialize.argtypes = L.qf_deserialize.argtypes = [vp, C.c_char_p]
+        if path:
+            L.qf_deserialize(C.byref(self.qf), path.encode())
+        else:
+            L.qf_init(C.byref(self.qf), 1 << qb, qb + 8, 0, True, b"", cqflibs.SEED)
+        self.p = C.byref(self.qf)
+
+    def insert(self, key, count=1):
+        nw = self.C.c_bool(False)
+        assert self.L.qf_insert_advance(self.p, key, 0, count, True, True, self.C.byref(nw))
+        return int(nw.value)
+
+    def count(self, key):
+        return self.L.qf_count_key_value(self.p, key, 0)
+
+    def count_set_traveled(self, key):
+        c = self.C.c_uint64()
+        t = self.L.qf_count_key_value_set_traveled(self.p, key, 0, self.C.byref(c))
+        return int(t), c.value
+
+    def blocks(self):
+        n = self.C.cast(self.qf.metadata, self.C.POINTER(self.C.c_uint64))[0]
+        return self.C.string_at(self.qf.blocks, n)
+
+    def dump(self):
+        it = self.QFi()
+        out = []
+        if not self.L.qf_iterator(self.p, self.C.byref(it), 0):
+            return out
+        k, v, c = self.C.c_uint64(), self.C.c_uint64(), self.C.c_uint64()
+        while True:
+            if self.L.qfi_get(self.C.byref(it), self.C.byref(k), self.C.byref(v), self.C.byref(c)):
+                break
+            out.append((k.value, c.value))
+            if self.L.qfi_next(self.C.byref(it)):
+                break
+        return out
+
+    def free(self):
+        self.L.qf_destroy(self.p, True)
+
+
+@pytest.mark.skipif(not cqflibs.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_gqf_named_host_api_against_the_compiled_reference(tmp_path):
+    """include/gqf_compat.h (libshkhost.so): qf_init / qf_insert_advance / qf_count_key_value / the traveled lookups /
+    find_first_* / qf_clean_singleton / check_offset / the qfi_* iterator / qf_serialize / qf_deserialize with the
+    reference's names and signatures, against the reference's own gqf.c on random scenarios: codec edge remainders,
+    counts to 2^21, dense clusters with saturated offsets, single inserts vs counted inserts, sweeps of whole clusters"""
+    import random
+    L = _hostlib()
+    R = cqflibs.ref()
+    rnd = random.Random(4)
+    for trial in range(30):
+        qb = rnd.choice([8, 9, 11])
+        a, r = _CompatQF(L, qb), R.new(qb)
+        tot = {}
+        n = int((1 << qb) * rnd.choice([0.15, 0.3, 0.45]))        # (x ~2 slots per key: the reference has no capacity check)
+        base = rnd.randrange(0, (1 << qb) - 80)
+        for i in range(n):
+            q = base + rnd.randrange(0, 64) if rnd.random() < 0.3 else rnd.randrange(1 << qb)      # a dense cluster + the rest
+            key = (q << 8) | rnd.choice([0, 1, 0x7f, 0x80, 0x81, 0xff, rnd.randrange(256)])
+            c = rnd.choice([1, 1, 1, 2, 3, 130, 16385, 1 << 21])
+            assert a.insert(key, c) == r.insert(key, c)
+            tot[key] = tot.get(key, 0) + c
+            if i % 97 == 0:
+                assert a.blocks() == r.blocks()
+        assert a.blocks() == r.blocks() and L.check_offset(a.p)
+        assert L.popcnt_occupieds(a.p) == len({k >> 8 for k in tot})
+        for x in range(0, (1 << qb) + 40, 5):
+            assert L.find_first_empty_slot(a.p, x) == r.find_first_empty_slot(x)
+            assert L.find_first_nonempty_slot(a.p, x) == r.find_first_nonempty_slot(x)
+        for key in list(tot)[:80] + [rnd.randrange(1 << (qb + 8)) for _ in range(80)]:
+            assert a.count(key) == r.count(key) == tot.get(key, 0)
+            assert a.count_set_traveled(key) == r.count_set_traveled(key)
+            assert a.count_set_traveled(key) == r.count_set_traveled(key)
+        assert a.blocks() == r.blocks()
+        assert a.dump() == r.dump()
+        # a round of the reference's sweep: cluster by cluster (find_first_nonempty_slot / find_first_empty_slot, CQF_mt.h:888-895)
+        import ctypes as C
+        rem = C.c_uint64(0)
+        cur = L.find_first_nonempty_slot(a.p, 0)
+        while cur < (1 << qb):
+            end = L.find_first_empty_slot(a.p, min(cur + 64, 1 << qb)) - 1
+            nxt = L.find_first_nonempty_slot(a.p, end + 1)
+            start = cur                                     # qf_clean_singleton_discrete (gqf.c:2878-2886): cluster by cluster; a
+            while start < end:                              # cluster that starts on the range's last slot is never visited
+                e = L.find_first_empty_slot(a.p, start + 1) - 1
+                L.qf_clean_singleton(a.p, start, e, C.byref(rem))
+                start = L.find_first_nonempty_slot(a.p, e + 1)
+            cur = nxt
+        assert rem.value == r.denoise_round(64)
+        assert a.blocks() == r.blocks() and L.check_offset(a.p)
+        p = str(tmp_path / "t.cqf")
+        L.qf_serialize(a.p, p.encode())
+        b = _CompatQF(L, path=p)
+        assert b.blocks() == a.blocks() and b.dump() == a.dump()
+        for x in (a, b, r):
+            x.free()
