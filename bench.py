@@ -78,7 +78,8 @@ def gen_batch_torch(torch, genome, nreads, L, err, first_id, seed, device):
     seq = genome[idx]                                          # codes 0..3
     strand = torch.randint(0, 2, (nreads, 1), generator=g, device=device, dtype=torch.uint8)
     seq = torch.where(strand.bool(), (3 - seq).flip(1), seq)   # reverse complement
-    e = torch.rand((nreads, L), generator=g, device=device) < err
+    # err: one rate, or a tensor of L per-position rates (an --errorProfile-like read model)
+    e = torch.rand((nreads, L), generator=g, device=device) < (err if isinstance(err, float) else err.to(device)[None, :])
     sub = torch.randint(1, 4, (nreads, L), generator=g, device=device, dtype=torch.uint8)
     seq = torch.where(e, (seq + sub) % 4, seq)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
@@ -450,7 +451,10 @@ def main():
             "build_time_s": dt, "build_kmers": counted, "build_rounds": rounds_fired,
             "config": {"workload": "clean CQF build from an empty filter: C.elegans-like synthetic reads (genome %d x n_gpus, L=150, e=0.00234), "
                                    "CQF-deNoise -k 47 -N %d -n %d -e 0.00234 -> qb=%d hb=%d rounds=%d trigger=%d (src/CQF-deNoise.cpp:96-161); "
-                                   "run with rounds=%d trigger=%d (rounds added until the predicted peak load %.3f <= %.2f, shk/plan.py); "
+                                   "run with rounds=%d trigger=%d (rounds added until the predicted peak load %.3f <= %.2f, shk/plan.py: the formula "
+                                   "budgets every false k-mer as removable, but error k-mers seen twice between two rounds stay -- at 100x "
+                                   "that is ~0.16 per genome k-mer, whatever the shape of the error profile (tests/test_plan.py), and the "
+                                   "README's own data has them too: f2 = 26.1 M -- so the recipe as written fills the table in its last step); "
                                    "%d steps x %d reads/step/GPU, 8 MiB chunks; warm-up on a scratch filter"
                                    % (args.genome, pl["N"], pl["n"], pl["qb"], pl["qb"] + 8, pl["formula_rounds"], pl["formula_trigger"],
                                       nd, trigger, pl["predicted_peak_load"], args.max_load, args.steps, R),

@@ -60,3 +60,19 @@ def test_planned_builds_fit(steps, world):
     if steps == 20 and world == 1:
         # BASELINE config 1: the README's table size and (nearly) its schedule
         assert pl["qb"] == 29 and pl["formula_rounds"] == 8 and pl["rounds"] <= 14
+
+
+@pytest.mark.parametrize("profile", [None, (0.0005, 0.00418)])
+def test_readme_recipe_overflows_whatever_the_error_spectrum(profile):
+    """is the 12-round plan an artefact of the uniform-substitution read model? The README recipe as
+    written (rounds and trigger straight from src/CQF-deNoise.cpp:96-161: 8 rounds), the whole 20-step build at 1/2048
+    scale on the oracle, with the bench's uniform error rate and with rates rising linearly along the read (mean unchanged,
+    what an --errorProfile file describes): the table fills up in the last step either way. What overflows it are error
+    k-mers seen TWICE between two rounds (they survive every later round; the formula budgets every false k-mer as
+    removable), and how often an error recurs depends on coverage x rate per genome position, which the shape of the
+    profile along the read does not change -- the README's own ntCard figures show the same population in the real data
+    (f2 = 26,122,317 doubletons next to n = 119,157,843 true k-mers, README.md:81-92)."""
+    r = _plan_check().run(scale=2048, steps=20, verbose=False, profile=profile)
+    assert (r["rounds"], r["fired"]) == (8, 8)
+    assert r["full_at_step"] is not None and r["full_at_step"] >= 17
+    assert r["pred_peak_load"] > 1.0

@@ -30,7 +30,9 @@ def used_slots(q):
     return int((1 + nd + esc).sum())
 
 
-def run(scale, steps, head=1.0, R0=8_000_000, G0=119_157_843, verbose=True, rounds=None, trigger=None):
+def run(scale, steps, head=1.0, R0=8_000_000, G0=119_157_843, verbose=True, rounds=None, trigger=None, profile=None):
+    """profile: None = the bench's uniform substitution rate; (lo, hi) = rates rising linearly along the read from lo to hi
+    (sequencing errors concentrate at the read end, as an --errorProfile file describes); the mean stays ERR"""
     import torch
     import cqflibs
     from shk import plan
@@ -50,12 +52,15 @@ def run(scale, steps, head=1.0, R0=8_000_000, G0=119_157_843, verbose=True, roun
     trigger = trigger or trig0
     pred = plan.predict_build(K, G, L, ERR, S / len(offs), len(offs) * steps, trigger, nd, trace_every=len(offs))
     dev = torch.device("cpu")
+    err_model = ERR if profile is None else torch.linspace(profile[0], profile[1], L, dtype=torch.float32)
+    if profile is not None:
+        assert abs(float(err_model.mean()) - ERR) < 1e-5
     genome = torch.randint(0, 4, (G,), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
     O = cqflibs.oracle()
     q = O.new(qb)
     left, fired, peak, full_at, per_step = nd, 0, 0, None, []
     for s in range(steps):
-        text = bench.gen_batch_torch(torch, genome, R, L, ERR, s * R, 1000 + s, dev).numpy().tobytes()
+        text = bench.gen_batch_torch(torch, genome, R, L, err_model, s * R, 1000 + s, dev).numpy().tobytes()
         for a, n in zip(offs, lens):
             q.reads_to_kmers(text[a:a + n], K)
             if q.full() and full_at is None:
