@@ -20,8 +20,10 @@
 #define SHK_EMPTY 0xFFFFFFFFu
 #define SHK_SUM_STRIDE 8
 #define SHK_SPILL_LENS SHK_REGION                                   // one length byte per quotient
-#define SHK_SPILL_STRIDE 1024                                        // + the lanes' staged run bytes, packed: a filled region needs
-                                                                     // about 200; one that needs more than the record holds is rebuilt from the list
+#define SHK_SPILL_STRIDE 768                                         // + the lanes' staged run bytes, packed: a filled region needs
+                                                                     // about 250 of the 512; one that needs more than the record holds is rebuilt from the list
+#define SHK_NC_CAP 128                                               // entries of a region's first-chunk record; a region with more new keys
+                                                                     // in one pass adds the rest to the chunk histogram directly
 #define SHK_SPILL_PACK_MAX (SHK_SPILL_STRIDE - SHK_SPILL_LENS)
 #define SHK_RSCAN_TILE 4096
 
@@ -54,7 +56,8 @@ struct ShkMergeArgs {
   uint32_t *over_list;            // regions whose runs did not fit the spill record (rebuilt by MODE 1 from this list)
   unsigned long long *n_over;
   const uint32_t *list;           // regions to rebuild (null = all: region = blockIdx.x + r0)
-  uint16_t *newchunks;            // [nregions * SHK_HCAP] first chunk of every NEW key of the region (null = off; needs want_hist)
+  uint16_t *newchunks;            // [nregions * SHK_NC_CAP] first chunk of every NEW key of the region (null = off; needs want_hist)
+  unsigned long long *chist;      // [SHK_MAX_CHUNKS] the chunk histogram k_chunk_hist sums the records into (zeroed BEFORE the pass: overflow adds here)
   // one-pass deNoise point (FUSED instantiation): words of chunks <= split are inserted BEFORE the round, the others after
   uint32_t split;
   uint32_t *isum;                 // [2 * nregions] (T, c) of the INTERMEDIATE table (after the chunks <= split, before the round)
@@ -692,16 +695,21 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   if (MODE != 1 && A.want_hist && A.newchunks && !fatal) {
     // first chunks of the region's new keys, compacted: k_chunk_hist turns them into the exact
     // per-chunk histogram from which the host reads the chunk of a deNoise point
-    uint16_t *nc = A.newchunks + (size_t)r * SHK_HCAP;
+    uint16_t *nc = A.newchunks + (size_t)r * SHK_NC_CAP;
     uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < nlist; i0 += SHK_WAVE) {     // nidx[0, nlist) = every hash slot in use
       const uint32_t h = i0 + tid < nlist ? nidx[i0 + tid] : 0;
       const bool f = i0 + tid < nlist && (hcnt[FUSED ? 2 * h + 1 : h] >> 31);
       const unsigned long long m = __ballot(f);
-      if (f) nc[base + (uint32_t)__popcll(m & ((1ULL << tid) - 1))] = (uint16_t)(hkey[h] & (SHK_MAX_CHUNKS - 1));
+      if (f) {
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ULL << tid) - 1));
+        const uint32_t ch = hkey[h] & (SHK_MAX_CHUNKS - 1);
+        if (at < SHK_NC_CAP) nc[at] = (uint16_t)ch;
+        else atomicAdd(&A.chist[ch], 1ULL);                 // (a region with more than SHK_NC_CAP new keys in one pass: rare)
+      }
       base += (uint32_t)__popcll(m);
     }
-    if (tid == 0) A.summary[(size_t)SHK_SUM_STRIDE * r + 7] = base;   // entries of this region's record (k_chunk_hist)
+    if (tid == 0) A.summary[(size_t)SHK_SUM_STRIDE * r + 7] = base < SHK_NC_CAP ? base : SHK_NC_CAP;   // entries of this region's record (k_chunk_hist)
   }
   if (MODE == 3) {
     // spill: 4 length bytes per lane, then the lanes' staged bytes back to back
@@ -1015,8 +1023,8 @@ __global__ void k_chunk_hist(const uint16_t *newchunks, const uint32_t *summary,
     if ((uint64_t)(r0 + i) * rstride >= nregions) break;
     const uint32_t r = (r0 + i) * rstride;                    // (rstride > 1: the sampled statistics pass)
     const uint32_t n = summary[(size_t)SHK_SUM_STRIDE * r + 7];
-    const uint16_t *nc = newchunks + (size_t)r * SHK_HCAP;
-    for (uint32_t j = lane; j < n && j < SHK_HCAP; j += SHK_WAVE) atomicAdd(&lh[nc[j]], 1u);
+    const uint16_t *nc = newchunks + (size_t)r * SHK_NC_CAP;
+    for (uint32_t j = lane; j < n && j < SHK_NC_CAP; j += SHK_WAVE) atomicAdd(&lh[nc[j]], 1u);
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < SHK_MAX_CHUNKS; i += blockDim.x)

@@ -554,7 +554,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   { const char *sp = getenv("SHK_STAMPS");    // diagnostics: "fused" = only the one-pass deNoise launches, "plain" = all the others, else all
     A->dbg = (sp && strcmp(sp, "fused") != 0) ? (unsigned long long *)(c->d_scalars + 16) : nullptr; }
   A->spill = c->d_spill; A->over_list = c->d_over_list; A->n_over = c->d_counters + 4 + SHK_HIST_BINS; A->list = nullptr;
-  A->newchunks = nullptr;
+  A->newchunks = nullptr; A->chist = nullptr;
   A->counted = c->counted;
   A->r0 = 0; A->rstride = 1;
   A->split = ~0u; A->isum = nullptr; A->ilens = nullptr; A->prot_list = nullptr; A->nprot = 0;
@@ -564,7 +564,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
 // first request for the exact first-chunk histogram (contexts that never reach a deNoise point never pay for it)
 static int ensure_chist(shk_ctx *c) {
   if (c->d_newchunks) return SHK_OK;
-  if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_HCAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
+  if (dmalloc(&c->d_newchunks, (uint64_t)c->nregions * SHK_NC_CAP) || dmalloc(&c->d_chist, (uint64_t)SHK_MAX_CHUNKS)) return SHK_ERR_HIP;
   HIPCHK(hipHostMalloc((void **)&c->h_chist, SHK_MAX_CHUNKS * sizeof(uint64_t), hipHostMallocDefault));
   return SHK_OK;
 }
@@ -579,7 +579,10 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
   c->spill_valid = 0;
   if (want_hist == 2 && !getenv("SHK_COARSE_HIST")) { int rc = ensure_chist(c); if (rc) return rc; }
   const bool exact = want_hist == 2 && c->d_newchunks;
-  if (exact) A.newchunks = c->d_newchunks;
+  if (exact) {   // (zeroed in front of the pass: regions whose record overflows add to the histogram themselves)
+    A.newchunks = c->d_newchunks; A.chist = c->d_chist;
+    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+  }
   o->have_chist = 0;
   if (spill) { ProfScope ps(c, KP_MERGE_SPILL);
     launch_merge<3>(c, A); }
@@ -593,7 +596,6 @@ static int merge_summary(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_
                        c->xnslots, (uint32_t)(c->big_image ? SHK_IMG_BLOCKS_BIG * 64 : SHK_IMG_SLOTS), c->fin[c->cur ^ 1], c->d_counters, c->d_err); }
   if (exact) {
     ProfScope ps(c, KP_MISC);
-    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
     hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
                        c->d_newchunks, c->d_summary, c->nregions, c->d_chist);
     HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -799,7 +801,10 @@ static int point_try(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t sp
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, 0, 0, 1, 0);
   A.split = split; A.isum = c->d_isum; A.ilens = c->d_ilens;
-  if (with_chist) { A.want_hist = 2; A.newchunks = c->d_newchunks; }
+  if (with_chist) {
+    A.want_hist = 2; A.newchunks = c->d_newchunks; A.chist = c->d_chist;
+    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
+  }
   { const char *sp = getenv("SHK_STAMPS");
     A.dbg = (sp && strcmp(sp, "plain") != 0) ? (unsigned long long *)(c->d_scalars + 16) : nullptr; }
   c->spill_valid = 0;
@@ -811,7 +816,6 @@ static int point_try(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t sp
   point_scans(c, true, true, 0);
   if (with_chist) {
     ProfScope ps(c, KP_MISC);
-    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
     hipLaunchKernelGGL(k_chunk_hist, dim3((c->nregions + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
                        c->d_newchunks, c->d_summary, c->nregions, c->d_chist, 1u);
     HIPCHK(hipMemcpyAsync(c->h_chist, c->d_chist, ((uint64_t)hi + 1) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -964,16 +968,16 @@ static int sample_pass(shk_ctx *c, const uint64_t *words, uint32_t lo, uint32_t 
   const uint32_t ns = (c->nregions + stride - 1) / stride;
   ShkMergeArgs A;
   fill_args(c, &A, words, lo, hi, lo, 0, 0, 2);
-  A.newchunks = c->d_newchunks; A.rstride = stride;
+  A.newchunks = c->d_newchunks; A.chist = c->d_chist; A.rstride = stride;
   c->spill_valid = 0;
   c->chist_n = 0;
+  HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
   { ProfScope ps(c, KP_MERGE_SAMPLE);
     for (uint32_t r0 = 0; r0 < ns; r0 += SHK_REGION_SLICE) {
       A.r0 = r0;
       const uint32_t nblk = ns - r0 < SHK_REGION_SLICE ? ns - r0 : SHK_REGION_SLICE;
       hipLaunchKernelGGL((k_region_merge<0, SHK_IMG_BLOCKS>), dim3(nblk), dim3(c->merge_group), 0, c->stream, A);
     }
-    HIPCHK(hipMemsetAsync(c->d_chist, 0, SHK_MAX_CHUNKS * 8, c->stream));
     hipLaunchKernelGGL(k_chunk_hist, dim3((ns + SHK_CHIST_REGIONS - 1) / SHK_CHIST_REGIONS), dim3(256), 0, c->stream,
                        c->d_newchunks, c->d_summary, c->nregions, c->d_chist, stride); }
   HIPCHK(hipGetLastError());
