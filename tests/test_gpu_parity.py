@@ -902,8 +902,11 @@ def _torch_reads(nreads, genome_len, err, seed):
 
 def _memory_report(ctx, nregions, batch_keys):
     t = ctx.totals()
-    return {"table_bytes_x2": 2 * t.table_bytes, "spill_records": nregions * 1024, "first_chunk_records": nregions * 1024,
-            "key_words_x2": 2 * 8 * batch_keys}
+    # (csrc/cqf_kernels.hip: SHK_SPILL_STRIDE = 768, SHK_NC_CAP = 128 entries of 2 bytes)
+    m = {"table_bytes_x2": 2 * t.table_bytes, "spill_records": nregions * 768, "first_chunk_records": nregions * 256,
+         "key_words_x2": 2 * 8 * batch_keys}
+    assert m["spill_records"] + m["first_chunk_records"] <= 1.5 * m["table_bytes_x2"]
+    return m
 
 
 def test_config4_one_shard_of_eight_human_sized(tmp_path):
