@@ -1118,3 +1118,24 @@ def test_multi_gpu_front_end_one_rank_over_rccl(tmp_path):
                             "--master-port", str(29650 + bi), "-m", "shk.count"] + args, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         assert open(out, "rb").read() == open(os.path.join(G, b["cqf"]), "rb").read(), (c, r.stderr[-600:])
+
+
+def test_qb34_whole_filter_context_fits_one_gpu():
+    """with 1 KiB of per-region records instead of 2 a WHOLE human-sized filter (qb 34: two 47.8 GB tables,
+    2^26 regions, 64 GiB of spill + first-chunk records) is created on one 288 GB MI355X, takes a batch and a deNoise round"""
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free < 200 * (1 << 30):
+        pytest.skip("needs ~170 GB of free HBM")
+    qb, k = 34, 31
+    fq = synth.make_fastq(synth.make_genome(50000, 3), 4000, 150, 0.01, seed=5)
+    offs, lens = chunks_by_records(fq, 500)
+    ctx = _ctx(qb=qb, k=k, trigger=1 << 40, num_denoise=2, max_batch_bytes=len(fq) + 1024, max_batch_keys=4000 * 150)
+    t = ctx.totals()
+    assert t.table_bytes == ((1 << qb) + int(10 * 2 ** (qb / 2)) + 63) // 64 * 89
+    st = ctx.count_chunks(fq, offs, lens)
+    assert st["kmers"] == 4000 * (150 - k + 1)
+    nd = ctx.totals().ndistinct
+    removed = ctx.denoise()
+    assert 0 < removed < nd and ctx.totals().ndistinct == nd - removed
+    ctx.close()
