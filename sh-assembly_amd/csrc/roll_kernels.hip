@@ -27,7 +27,8 @@ struct ShkRollArgs {
   uint32_t chunk_first, chunk_mul, k, hb;
   uint64_t q_lo;
   uint32_t dig_shift, dig_bits;    // first partition level: digit = (region >> dig_shift) & (2^dig_bits - 1)
-  uint64_t *hist;                  // k_roll_hist: 2^dig_bits counters
+  uint32_t hist_shift, hist_bits;  // k_roll_hist: bin = (region >> hist_shift) & (2^hist_bits - 1)
+  uint64_t *hist;                  // k_roll_hist: 2^hist_bits counters
   uint64_t *cursor;                // k_roll_scatter: next free position of every digit's bucket (starts at its base)
   uint64_t *out;
   uint64_t cap;                    // words `out` holds
@@ -199,28 +200,42 @@ __device__ __forceinline__ uint32_t shk_roll_digit(uint64_t key, const ShkRollAr
   return (region >> A.dig_shift) & ((1u << A.dig_bits) - 1);
 }
 
-// pass 1: digit histogram (and, as its sum, the number of keys)
-__global__ void __launch_bounds__(256) k_roll_hist(ShkRollArgs A) {
+// pass 1: digit histogram (and, as its sum, the number of keys). LB = log2 of the LDS bins: 10 for the first level's
+// digits alone; 14 when the first TWO levels' digits fit (7 + 7 bits for a qb-29 filter): the histogram of the second
+// partition level then comes out of this pass too and its own pass over the keys (k_rp_hist, 1.1 ms) is not needed
+// (hist_shift / hist_bits describe the combined digit; k_roll_fold sums it down to the first level's counts).
+template <int LB, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_roll_hist(ShkRollArgs A) {
   __shared__ ShkRollTabs T;
-  __shared__ uint32_t lh[1024];
+  __shared__ uint32_t lh[1u << LB];
   shk_roll_tabs_init(&T, A.k);
-  const uint32_t P = 1u << A.dig_bits;
+  const uint32_t P = 1u << A.hist_bits;
   for (uint32_t d = threadIdx.x; d < P; d += blockDim.x) lh[d] = 0;
   __syncthreads();
   const uint64_t nreads = *A.nreads_p;
   const uint64_t mask = A.hb >= 64 ? ~0ULL : ((1ULL << A.hb) - 1);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t qlo16 = (uint32_t)(A.q_lo >> 8);
   for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
     const uint64_t st = A.rd_start[r], en = A.rd_end[r];
     if (en - st > 65535) { atomicOr(A.err, SHK_E_BAD_FASTQ); continue; }     // SHK_MAX_READ
     if (en - st < A.k) continue;
     ShkRollState s;
     s.st = st; s.len = (uint32_t)(en - st); s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
-    while (shk_roll_round<4>(&T, A.text, A.safe_end, s, A.k, mask, [&](int, uint64_t key) { atomicAdd(&lh[shk_roll_digit(key, A)], 1u); })) {}
+    while (shk_roll_round<4>(&T, A.text, A.safe_end, s, A.k, mask, [&](int, uint64_t key) {
+      atomicAdd(&lh[(((uint32_t)(key >> 16) - qlo16) >> A.hist_shift) & (P - 1)], 1u); })) {}
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
     if (lh[d]) atomicAdd((unsigned long long *)&A.hist[d], (unsigned long long)lh[d]);
+}
+// first-level counts from the two-level histogram: hist0[d] = sum of hist2[d * P1 .. (d + 1) * P1)
+__global__ void k_roll_fold(const uint64_t *hist2, uint32_t p0, uint32_t p1, uint64_t *hist0) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= p0) return;
+  uint64_t t = 0;
+  for (uint32_t j = 0; j < p1; j++) t += hist2[(uint64_t)d * p1 + j];
+  hist0[d] = t;
 }
 
 // pass 2: the keys again, straight into their buckets. THREADS x 16 keys per window.

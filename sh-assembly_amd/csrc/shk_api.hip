@@ -416,22 +416,38 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
 // d_scalars[1] = #words (roll_kernels.hip). For contexts with at least two partition levels.
 static bool roll_path(const shk_ctx *c) { return c->nlevels >= 2 && (c->q_lo & (SHK_REGION - 1)) == 0 && !getenv("SHK_NO_ROLL"); }
 static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text_bytes, const uint64_t *chunk_off,
-                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul) {
+                      const uint64_t *chunk_len, uint32_t nchunks, uint32_t chunk_first, uint32_t chunk_mul, bool *level1_hist_ready) {
   if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
   const uint8_t *dtext;
   uint64_t nreads;
   { int rc = parse_stage(c, text, on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads); if (rc) return rc; }
   const uint64_t P = 1ULL << c->lv[0].bits;
-  HIPCHK(hipMemsetAsync(c->d_hist[0], 0, P * 8, c->stream));
+  // the first two levels' digits together, when they fit the histogram pass's LDS bins
+  const uint32_t cb = c->lv[0].bits + c->lv[1].bits;
+  const bool two = cb <= 14 && !getenv("SHK_ROLL_HIST1");
+  *level1_hist_ready = two;
+  if (two) HIPCHK(hipMemsetAsync(c->d_hist[1], 0, (1ULL << cb) * 8, c->stream));
+  else HIPCHK(hipMemsetAsync(c->d_hist[0], 0, P * 8, c->stream));
   ShkRollArgs A;
   A.text = dtext; A.safe_end = (text_bytes + 15) & ~15ULL;
   A.rd_start = c->d_rd_start; A.rd_end = c->d_rd_end; A.nreads_p = c->d_scalars + 0; A.rd_chunk = c->d_rd_chunk;
   A.chunk_first = chunk_first; A.chunk_mul = chunk_mul; A.k = c->cfg.k; A.hb = c->cfg.hb; A.q_lo = c->q_lo;
   A.dig_shift = c->lv[0].shift; A.dig_bits = c->lv[0].bits;
-  A.hist = c->d_hist[0]; A.cursor = c->d_cursor; A.out = c->d_words[0]; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
+  A.hist = two ? c->d_hist[1] : c->d_hist[0]; A.hist_shift = two ? c->lv[1].shift : c->lv[0].shift; A.hist_bits = two ? cb : c->lv[0].bits;
+  A.cursor = c->d_cursor; A.out = c->d_words[0]; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
   { ProfScope ps(c, KP_ROLL_HIST);
-    const uint64_t blocks = nreads / 256 + 1;
-    hipLaunchKernelGGL(k_roll_hist, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, c->stream, A); }
+    if (two && c->threads >= 512) {
+      const uint64_t blocks = nreads / 512 + 1;
+      hipLaunchKernelGGL((k_roll_hist<14, 512>), dim3((uint32_t)(blocks < 1024 ? blocks : 1024)), dim3(512), 0, c->stream, A);
+    } else if (two) {     // (small workgroups: the CPU emulator build of the tests)
+      const uint64_t blocks = nreads / 64 + 1;
+      hipLaunchKernelGGL((k_roll_hist<14, 64>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
+    } else {
+      const uint64_t blocks = nreads / 256 + 1;
+      hipLaunchKernelGGL((k_roll_hist<10, 256>), dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, c->stream, A);
+    }
+    if (two) hipLaunchKernelGGL(k_roll_fold, dim3((uint32_t)(P / 256 + 1)), dim3(256), 0, c->stream, (const uint64_t *)c->d_hist[1], (uint32_t)P,
+                                1u << c->lv[1].bits, c->d_hist[0]); }
   // bucket bases = exclusive scan of the digit counts; its total is the number of key words
   if (run_scan<uint64_t>(c, c->d_hist[0], P, nullptr, c->d_base[1])) return SHK_ERR_HIP;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->d_base[1] + P, 8, hipMemcpyDeviceToDevice, c->stream));
@@ -466,7 +482,7 @@ static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
 // first_level = 1: the words in d_words[src] are partitioned by the first digit already and d_base[1] holds the bucket
 // bases (roll_stage)
 static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const uint64_t *ext = nullptr, bool hist0_ready = false,
-                           uint32_t first_level = 0) {
+                           uint32_t first_level = 0, bool hist1_ready = false) {
   const uint64_t *n_p = c->d_scalars + 1;
   { ProfScope ps(c, KP_RP_PREP);
     hipLaunchKernelGGL(k_rp_base1, dim3(1), dim3(64), 0, c->stream, n_p, c->d_base[0]); }
@@ -477,8 +493,8 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
     { ProfScope ps(c, KP_RP_PREP);
       hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
-      if (!(l == 0 && hist0_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream)); }
-    if (!(l == 0 && hist0_ready)) { ProfScope ps(c, KP_RP_HIST);
+      if (!(l == 0 && hist0_ready) && !(l == 1 && hist1_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream)); }
+    if (!(l == 0 && hist0_ready) && !(l == 1 && hist1_ready)) { ProfScope ps(c, KP_RP_HIST);
       const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
       hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
     if (c->lv[l].ng_log2) {
@@ -1235,7 +1251,8 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   memset(&st, 0, sizeof(st));
   HIPCHK(hipSetDevice(c->dev));
   const bool roll = roll_path(c);
-  int rc = roll ? roll_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1)
+  bool h1 = false;
+  int rc = roll ? roll_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1, &h1)
                 : hash_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, 0, 1, true);
   if (rc) return finish(c, rc);
   uint32_t bits = 0;
@@ -1246,7 +1263,7 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
   if (nwords > c->cfg.max_batch_keys) { prof_collect(c); return SHK_ERR_BATCH; }
   int dst = 0;
   // (the roll kernels leave the words partitioned by the first digit; the hash kernel has counted the first level's digits)
-  rc = roll ? partition_stage(c, 0, nwords, &dst, nullptr, false, 1) : partition_stage(c, 0, nwords, &dst, nullptr, true);
+  rc = roll ? partition_stage(c, 0, nwords, &dst, nullptr, false, 1, h1) : partition_stage(c, 0, nwords, &dst, nullptr, true);
   if (rc) return finish(c, rc);
   rc = merge_stage(c, c->d_words[dst], nchunks, nwords, &st);
   if (stats) *stats = st;
@@ -1369,7 +1386,8 @@ static void front_run(shk_ctx *c, ShkFrontSlot *S, const void *text, int on_devi
   const uint32_t nchunks = (uint32_t)off.size();
   const bool roll = roll_path(c);
   S->nwords = 0; S->nchunks = nchunks;
-  int rc = roll ? roll_stage(f, text, on_device, text_bytes, off.data(), len.data(), nchunks, 0, 1)
+  bool h1 = false;
+  int rc = roll ? roll_stage(f, text, on_device, text_bytes, off.data(), len.data(), nchunks, 0, 1, &h1)
                 : hash_stage(f, text, on_device, text_bytes, off.data(), len.data(), nchunks, 0, 1, true);
   uint32_t bits = 0;
   if (!rc) {
@@ -1380,7 +1398,7 @@ static void front_run(shk_ctx *c, ShkFrontSlot *S, const void *text, int on_devi
   if (!rc) {
     S->nwords = f->h_pinned[42];
     int dst = 0;
-    rc = roll ? partition_stage(f, 0, S->nwords, &dst, nullptr, false, 1) : partition_stage(f, 0, S->nwords, &dst, nullptr, true);
+    rc = roll ? partition_stage(f, 0, S->nwords, &dst, nullptr, false, 1, h1) : partition_stage(f, 0, S->nwords, &dst, nullptr, true);
     S->dst = dst;
     if (!rc) {
       if (fetch_err(f, &bits)) rc = SHK_ERR_HIP;          // (synchronises the shadow's stream: the batch is ready)

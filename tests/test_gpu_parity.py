@@ -1128,7 +1128,7 @@ def test_qb34_whole_filter_context_fits_one_gpu():
     if free < 200 * (1 << 30):
         pytest.skip("needs ~170 GB of free HBM")
     qb, k = 34, 31
-    fq = synth.make_fastq(synth.make_genome(50000, 3), 4000, 150, 0.01, seed=5)
+    fq = synth.make_fastq(synth.make_genome(50000, 3), 4000, 150, 0.01, seed=5, n_frac=0.0)
     offs, lens = chunks_by_records(fq, 500)
     ctx = _ctx(qb=qb, k=k, trigger=1 << 40, num_denoise=2, max_batch_bytes=len(fq) + 1024, max_batch_keys=4000 * 150)
     t = ctx.totals()
