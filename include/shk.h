@@ -172,6 +172,14 @@ typedef struct shk_summary {
  * counts[o] words for owner o -- the send buffer of the all-to-all. Two send buffers alternate: the result of one
  * call stays valid until the SECOND-next call, so batch s can be on the wire while batch s+1 is hashed and routed. */
 int shk_route_words(shk_ctx *ctx, uint64_t nwords, uint32_t nshards, uint64_t **d_out, uint64_t *counts);
+
+/* shk_hash_chunks + shk_route_words in one pass over the text: every k-mer is hashed and sent straight to its owner's
+ * bin of one of the two alternating send buffers (no key word goes to HBM and back in between). Same results:
+ * `*d_out` holds the words binned by owner, counts[s] of them for shard s, `*nwords` in total; chunk i of the call is
+ * labelled i * num_shards + shard_index. */
+int shk_hash_route_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
+                          const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks, uint32_t nshards,
+                          uint64_t **d_out, uint64_t *counts, uint64_t *nwords);
 int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                       int want_hist, shk_summary *out);

@@ -1580,6 +1580,74 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   return finish(c, 0);
 }
 
+// shk_hash_chunks + shk_route_words in one: the roll kernels (roll_kernels.hip) hash every k-mer and send it straight
+// to its OWNER's bin of the send buffer (digit = the top log2(nshards) bits of the whole filter's regions) -- no key word
+// is written to HBM and read back before the exchange. Chunk i is labelled i * num_shards + shard_index as in
+// shk_hash_chunks.
+extern "C" int shk_hash_route_chunks(shk_ctx *c, const void *text, int text_on_device, uint64_t text_bytes, const uint64_t *chunk_off,
+                                     const uint64_t *chunk_len, uint32_t nchunks, uint32_t nshards, uint64_t **d_out, uint64_t *counts,
+                                     uint64_t *nwords) {
+  if (!c || !text || !chunk_off || !chunk_len || !d_out || !counts || !nwords) return SHK_ERR_ARG;
+  if (nshards == 0 || (nshards & (nshards - 1)) || nshards > SHK_RP_MAXP) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  uint32_t lg = 0;
+  while ((1u << lg) < nshards) lg++;
+  if (c->cfg.qb < SHK_REGION_LOG2 + lg) return SHK_ERR_ARG;
+  const uint32_t chunk_first = c->cfg.shard_index, chunk_mul = c->cfg.num_shards ? c->cfg.num_shards : 1;
+  if (nchunks == 0 || nchunks > SHK_MAX_CHUNKS || chunk_first + (uint64_t)(nchunks - 1) * chunk_mul >= SHK_MAX_CHUNKS) return SHK_ERR_BATCH;
+  uint64_t *send = c->d_words[1];
+  if (!getenv("SHK_ROUTE_SINGLE_BUFFER")) {
+    const int b = c->send_next;
+    if (!c->d_send[b] && dmalloc(&c->d_send[b], c->cfg.max_batch_keys + 1)) return SHK_ERR_HIP;
+    send = c->d_send[b];
+    c->send_next ^= 1;
+  }
+  const uint8_t *dtext;
+  uint64_t nreads;
+  int rc = parse_stage(c, text, text_on_device, text_bytes, chunk_off, chunk_len, nchunks, &dtext, &nreads);
+  if (rc) return finish(c, rc);
+  uint64_t *hist = c->d_block_sums;            // scratch: nshards <= 1024 words each
+  uint64_t *cursor = c->d_block_sums + 4096;
+  HIPCHK(hipMemsetAsync(hist, 0, nshards * 8, c->stream));
+  ShkRollArgs A;
+  A.text = dtext; A.safe_end = (text_bytes + 15) & ~15ULL;
+  A.rd_start = c->d_rd_start; A.rd_end = c->d_rd_end; A.nreads_p = c->d_scalars + 0; A.rd_chunk = c->d_rd_chunk;
+  A.chunk_first = chunk_first; A.chunk_mul = chunk_mul; A.k = c->cfg.k; A.hb = c->cfg.hb;
+  A.q_lo = 0;                                   // (owners are ranges of the WHOLE filter's quotients)
+  A.dig_shift = (c->cfg.qb - SHK_REGION_LOG2) - lg; A.dig_bits = lg;
+  A.hist_shift = A.dig_shift; A.hist_bits = lg;
+  A.hist = hist; A.cursor = cursor; A.out = send; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
+  { ProfScope ps(c, KP_ROLL_HIST);
+    if (c->threads >= 512) {
+      const uint64_t blocks = nreads / 256 + 1;
+      hipLaunchKernelGGL((k_roll_hist<10, 256>), dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, c->stream, A);
+    } else {
+      const uint64_t blocks = nreads / 64 + 1;
+      hipLaunchKernelGGL((k_roll_hist<10, 64>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
+    } }
+  std::vector<uint64_t> hh(nshards);
+  HIPCHK(hipMemcpyAsync(hh.data(), hist, nshards * 8, hipMemcpyDeviceToHost, c->stream));
+  uint32_t bits = 0;
+  if (fetch_err(c, &bits)) return SHK_ERR_HIP;
+  if (bits) { prof_collect(c); return map_err_bits(bits); }
+  std::vector<uint64_t> bb(nshards + 1, 0);
+  for (uint32_t i = 0; i < nshards; i++) { counts[i] = hh[i]; bb[i + 1] = bb[i] + hh[i]; }
+  *nwords = bb[nshards];
+  if (bb[nshards] > c->cfg.max_batch_keys) { prof_collect(c); return SHK_ERR_BATCH; }
+  HIPCHK(hipMemcpyAsync(cursor, bb.data(), nshards * 8, hipMemcpyHostToDevice, c->stream));
+  { ProfScope ps(c, KP_ROLL_SCATTER);
+    if (c->threads >= 512) {
+      const uint64_t blocks = nreads / 1024 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<1024, 1>), dim3((uint32_t)(blocks < 512 ? blocks : 512)), dim3(1024), 0, c->stream, A);
+    } else {
+      const uint64_t blocks = nreads / 64 + 1;
+      hipLaunchKernelGGL((k_roll_scatter<64, 4>), dim3((uint32_t)(blocks < 64 ? blocks : 64)), dim3(64), 0, c->stream, A);
+    } }
+  HIPCHK(hipGetLastError());
+  *d_out = send;
+  return finish(c, 0);
+}
+
 extern "C" int shk_stage_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwords) {
   if (!c || (!d_words && nwords)) return SHK_ERR_ARG;
   if (nwords > c->cfg.max_batch_keys) return SHK_ERR_BATCH;

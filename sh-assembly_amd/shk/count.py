@@ -133,15 +133,11 @@ def main(argv=None):
 
     def start(first_global):
         text, offs, lens, seen, err = next_batch(first_global)
-        rc = -6 if err else 0                      # SHK_ERR_IO: "Error: Wrong input file!"
-        nw = 0
-        if not rc and offs:
-            try:
-                _, nw = ctx.hash_chunks(text, offs, lens)
-            except shk.ShkError as e:
-                rc = e.code
-        # (a rank without a part in the last, ragged batch still takes part in the exchange with no words)
-        return shkdist.Exchange(ctx, nw, qb + 8, world, rank, device, local_rc=rc), seen
+        if err:                                    # SHK_ERR_IO: "Error: Wrong input file!"
+            return shkdist.Exchange(ctx, 0, qb + 8, world, rank, device, local_rc=-6), seen
+        # hash + bin by owner + start the exchange (a rank without a part in the last, ragged batch takes part with no
+        # words; a local failure is raised on every rank)
+        return shkdist.hash_and_exchange(ctx, text, offs, lens, qb + 8, world, rank, device), seen
 
     hb = qb + 8
     first = 0

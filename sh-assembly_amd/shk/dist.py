@@ -506,12 +506,15 @@ class Exchange:
     two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
     behind compute: xGMI moves 8 B per routed key while the CUs hash."""
 
-    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True, local_rc=0):
+    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True, local_rc=0, routed=None):
         # local_rc: the return code of the rank-local work in front of this exchange (shk_hash_chunks), 0 = fine.
         # A rank-local failure -- there, or in shk_route_words here -- must not keep this rank out of the all-gather its
         # peers enter: the code travels in the gathered vector (one extra column) and EVERY rank raises after the gather.
+        # routed = (device pointer, counts per shard): the words are binned already (shk_hash_route_chunks)
         rc, dp, sc = int(local_rc), None, [0] * world
-        if not rc:
+        if not rc and routed is not None:
+            dp, sc = routed
+        elif not rc:
             try:
                 dp, sc = ctx.route_words(nwords, world)
             except ShkError as e:
@@ -575,12 +578,17 @@ class Exchange:
 
 def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=False, text_bytes=None, async_op=True):
     """shk_hash_chunks + Exchange with the rank-local failure of either carried to every rank (see Exchange)"""
-    rc, nw = 0, 0
+    rc, nw, routed = 0, 0, None
     try:
-        _, nw = ctx.hash_chunks(text, offs, lens, on_device=on_device, text_bytes=text_bytes)
+        if offs and not os.environ.get("SHK_NO_ROLL"):
+            # one pass over the text: every k-mer hashed and sent straight to its owner's bin of the send buffer
+            dp, sc, nw = ctx.hash_route_chunks(text, offs, lens, world, on_device=on_device, text_bytes=text_bytes)
+            routed = (dp, sc)
+        elif offs:
+            _, nw = ctx.hash_chunks(text, offs, lens, on_device=on_device, text_bytes=text_bytes)
     except ShkError as e:
         rc = e.code
-    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc)
+    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc, routed=routed)
 
 
 def stage_received(ctx, st, recv):

@@ -80,8 +80,11 @@ def main():
         try:
             for i in range(0, len(offs), step):
                 if args.sharded:
-                    _, nw = ctx.hash_chunks(fq, offs[i:i + step], lens[i:i + step])
-                    recv = shkdist.route_words(ctx, nw, qb + 8, 1, 0, dev)
+                    if rnd.random() < 0.5:      # hash + bin by owner in one pass (roll kernels) ...
+                        recv = shkdist.hash_and_exchange(ctx, fq, offs[i:i + step], lens[i:i + step], qb + 8, 1, 0, dev, async_op=False).wait()
+                    else:                       # ... or the wave-scan hash kernel and the routing pass
+                        _, nw = ctx.hash_chunks(fq, offs[i:i + step], lens[i:i + step])
+                        recv = shkdist.route_words(ctx, nw, qb + 8, 1, 0, dev)
                     ctx.stage_words(recv.data_ptr(), recv.numel())
                     st = shkdist.sharded_count(ctx, sst, len(offs[i:i + step]))
                 else:
