@@ -301,6 +301,8 @@ def main():
 
         def __init__(self):
             self.ctx = new_ctx()
+            if not sharded and not args.serial and not args.host_text:
+                self.ctx.prepare_reserve()       # (the overlapped front end's buffers: context set-up, like the table's own)
             self.sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
             self.counted = self.removed = self.rounds = 0
             self.uploaded = {}

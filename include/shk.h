@@ -124,6 +124,9 @@ int shk_count_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_
 int shk_prepare_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint64_t text_bytes,
                        const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks);
 int shk_count_prepared(shk_ctx *ctx, shk_batch_stats *stats);
+/* Allocates the front end's own buffers and stream now instead of inside the first shk_prepare_chunks (which does it
+ * otherwise): for callers that want context set-up and steady state apart, e.g. when timing. Idempotent. */
+int shk_prepare_reserve(shk_ctx *ctx);
 
 /* Overlapped ingest: start copying host text (pinned memory for full PCIe rate) for a LATER call into one of two
  * context-owned device buffers; the copy runs on its own stream while the context computes. Pass the returned

@@ -25,13 +25,13 @@
 
 // seedTab / msTab column 0 (nthash.hpp:85-153): upper and lower case map, all else is 0
 __device__ __forceinline__ uint64_t shk_seed_fwd(unsigned c) {
-  c &= 0xDF;
-  return c == 'A' ? SHK_SEED_A : c == 'C' ? SHK_SEED_C : c == 'G' ? SHK_SEED_G : c == 'T' ? SHK_SEED_T : 0ULL;
+  const unsigned u = c & 0xDF;
+  return (u == 'A' || c == 4) ? SHK_SEED_A : (u == 'C' || c == 7) ? SHK_SEED_C : (u == 'G' || c == 3) ? SHK_SEED_G : (u == 'T' || c == 1) ? SHK_SEED_T : 0ULL;
 }
-// seed of the complement base: the reference indexes with (c & cpOff), nthash.hpp:15,299
+// seed on the complement strand: the reference indexes seedTab with (c & cpOff) for every byte, nthash.hpp:15,299
 __device__ __forceinline__ uint64_t shk_seed_rc(unsigned c) {
-  c &= 0xDF;
-  return c == 'A' ? SHK_SEED_T : c == 'C' ? SHK_SEED_G : c == 'G' ? SHK_SEED_C : c == 'T' ? SHK_SEED_A : 0ULL;
+  c &= 7;
+  return c == 1 ? SHK_SEED_T : c == 3 ? SHK_SEED_G : c == 7 ? SHK_SEED_C : c == 4 ? SHK_SEED_A : 0ULL;
 }
 
 // exact per-byte "== '\n'" flags (0x80 in every matching byte)
@@ -336,9 +336,11 @@ __global__ void k_hash_reads(const uint8_t *text, const uint64_t *rd_start, cons
         if (j < L) {
           // the first segment's first four strips are already in registers
           const uint32_t raw = (s == 0 && t < 4) ? (t == 0 ? pc[0] : t == 1 ? pc[1] : t == 2 ? pc[2] : pc[3]) : (uint32_t)rd[s + j];
-          const unsigned ch = raw & 0xDF;   // upper and lower case map alike (nthash.hpp:85-153); all else is 0
-          a = ch == 'A' ? fA : ch == 'C' ? fC : ch == 'G' ? fG : ch == 'T' ? fT : 0ULL;
-          c = ch == 'A' ? rA : ch == 'C' ? rC : ch == 'G' ? rG : ch == 'T' ? rT : 0ULL;
+          // seedTab (nthash.hpp:120-153): the bases in either case and the bytes 1 3 4 7; the complement strand's
+          // seed is seedTab[byte & 7] for EVERY byte (nthash.hpp:299), base or not
+          const unsigned b8 = raw & 0xFF, ch = b8 & 0xDF, lo = b8 & 7;
+          a = (ch == 'A' || b8 == 4) ? fA : (ch == 'C' || b8 == 7) ? fC : (ch == 'G' || b8 == 3) ? fG : (ch == 'T' || b8 == 1) ? fT : 0ULL;
+          c = lo == 1 ? rA : lo == 3 ? rC : lo == 7 ? rG : lo == 4 ? rT : 0ULL;
         }
         const uint64_t G1 = shk_wave_incl_xor64(a) ^ carryG;  // G(j+1)
         const uint64_t H1 = shk_wave_incl_xor64(c) ^ carryH;  // H(j+1)

@@ -33,6 +33,11 @@ struct ShkRollArgs {
   uint64_t *out;
   uint64_t cap;                    // words `out` holds
   uint32_t *err;
+  // 2-bit staging (k_pack_reads), null = none: read r's bases, 64 per 16-byte unit, start at unit pk_base[r];
+  // pk_flag[r] = its number of units (0 = too short or too long a read), bit 31 set = holds a byte that is no base
+  const struct ShkQuad *pk;
+  const uint64_t *pk_base;
+  const uint32_t *pk_flag;
 };
 
 // The two tables in LDS, indexed by the raw BYTE (no code lookup in between): row c of `in` = {seed[c], rol(seedc[c], k-1)},
@@ -40,15 +45,25 @@ struct ShkRollArgs {
 struct ShkRollRow { uint64_t f, r; };
 struct ShkRollTabs {
   ShkRollRow in[256], out[256];
+  ShkRollRow in4[4], out4[4];      // the same rows by 2-bit code (A C G T = 0 1 2 3), for reads staged by k_pack_reads
 };
 __device__ __forceinline__ void shk_roll_tabs_init(ShkRollTabs *t, uint32_t k) {
   const uint64_t sf[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL};  // A C G T, nthash.hpp:24-27
   for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    const uint32_t u = i & 0xDF;
-    const int b = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : -1;
-    const uint64_t f = b >= 0 ? sf[b] : 0, c = b >= 0 ? sf[3 - b] : 0;   // complement: A<->T, C<->G (cpOff, nthash.hpp:15)
+    // seedTab (nthash.hpp:120-153): the bases in either case, and the bytes 1 3 4 7 = their images under `& cpOff`
+    // (nthash.hpp:15). The strand of the complement is looked up with seedTab[c & 7] for EVERY byte (nthash.hpp:245,
+    // 299, 307): 'A' & 7 = 1 -> T, 'C' -> 3 -> G, 'G' -> 7 -> C, 'T' -> 4 -> A -- and a byte that is no base still
+    // contributes there when its low bits are one of those ('Y', 'K', 'S', 'W', 'D' ... of the IUPAC codes do; 'N' does not)
+    const uint32_t u = i & 0xDF, lo = i & 7;
+    const int b = (u == 'A' || i == 4) ? 0 : (u == 'C' || i == 7) ? 1 : (u == 'G' || i == 3) ? 2 : (u == 'T' || i == 1) ? 3 : -1;
+    const int bc = lo == 1 ? 3 : lo == 3 ? 2 : lo == 7 ? 1 : lo == 4 ? 0 : -1;
+    const uint64_t f = b >= 0 ? sf[b] : 0, c = bc >= 0 ? sf[bc] : 0;
     t->in[i].f = f; t->in[i].r = shk_rol64(c, k - 1);
     t->out[i].f = shk_rol64(f, k); t->out[i].r = shk_ror64(c, 1);
+    if (i < 4) {
+      t->in4[i].f = sf[i]; t->in4[i].r = shk_rol64(sf[3 - i], k - 1);
+      t->out4[i].f = shk_rol64(sf[i], k); t->out4[i].r = shk_ror64(sf[3 - i], 1);
+    }
   }
 }
 // rotations by one as funnel shifts of the halves (v_alignbit_b32 each; the 64-bit shifts run at a quarter of the rate)
@@ -193,6 +208,131 @@ __device__ __forceinline__ bool shk_roll_round(const ShkRollTabs *T, const uint8
   return true;
 }
 
+// ---- 2-bit staging -------------------------------------------------------------------------------------------------
+// The two passes above re-read the FASTQ text thread by thread: a wave's 64 reads lie ~330 bytes apart, every lane pulls
+// its own 128-byte lines, and with half a million threads in flight no line survives in L2 until its owner's next round
+// (measured: 18 GB fetched per 2.6 GB of text, profiles/r03_a). k_pack_reads reads the text ONCE, coalesced, and leaves
+// every read that is all bases as 2 bits per base, 64 bases per 16-byte unit, units of consecutive reads adjacent: the
+// passes then take 16 bytes per four rounds from lines their neighbours use too, and a read that holds anything else
+// (an 'N', any other byte: rare) stays on the text path above, which treats it exactly as reads_to_kmers does.
+// code = A C G T -> 0 1 2 3 (either case): ((c >> 1) ^ (c >> 2)) & 3.
+__global__ void k_pack_count(const uint64_t *rd_start, const uint64_t *rd_end, const uint64_t *nreads_p, uint32_t k, uint32_t *units) {
+  const uint64_t nreads = *nreads_p;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += stride) {
+    const uint64_t len = rd_end[r] - rd_start[r];
+    units[r] = (len >= k && len <= 65535) ? (uint32_t)((len + 63) >> 6) : 0;
+  }
+}
+// bytes of v that are zero -> 0x80 (exactly those)
+__device__ __forceinline__ uint32_t shk_zero_bytes(uint32_t v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+// four lanes per read, one 64-base unit per lane and turn
+__global__ void k_pack_reads(const uint8_t *text, uint64_t safe_end, const uint64_t *rd_start, const uint64_t *rd_end, const uint64_t *nreads_p,
+                             const uint64_t *pk_base, uint32_t *flag, ShkQuad *pk, uint64_t cap_units) {
+  const uint64_t nreads = *nreads_p;
+  const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+  for (uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; r < nreads; r += stride) {
+    const uint32_t units = flag[r] & 0x7FFFFFFFu;
+    if (!units) continue;
+    const uint64_t base = pk_base[r];
+    if (base + units > cap_units) { if ((threadIdx.x & 3) == 0) atomicOr(&flag[r], 0x80000000u); continue; }   // (overlapping chunks: more bases than text)
+    const uint64_t st = rd_start[r];
+    const uint32_t len = (uint32_t)(rd_end[r] - st);
+    uint32_t bad = 0;
+    for (uint32_t u = threadIdx.x & 3; u < units; u += 4) {
+      uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t pos = 64 * u + 16 * q;
+        if (pos < len) {
+          const ShkQuad v = shk_load16(text, st + pos, safe_end);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const uint32_t y = w[b] & 0xDFDFDFDFu;
+            const uint32_t ok = shk_zero_bytes(y ^ 0x41414141u) | shk_zero_bytes(y ^ 0x43434343u) | shk_zero_bytes(y ^ 0x47474747u) |
+                                shk_zero_bytes(y ^ 0x54545454u);
+            const uint32_t left = len - pos > 4u * b ? len - pos - 4u * b : 0;      // bytes of this word inside the read
+            const uint32_t need = left >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * left)) - 1));
+            bad |= need & ~ok;
+            const uint32_t x = ((w[b] >> 1) ^ (w[b] >> 2)) & 0x03030303u;          // four codes, one per byte
+            o[q] |= ((x * 0x01041040u) >> 24) << (8 * b);                          // ... gathered into one byte
+          }
+        }
+      }
+      pk[base + u] = shk_quad(o[0], o[1], o[2], o[3]);
+    }
+    if (bad) atomicOr(&flag[r], 0x80000000u);
+  }
+}
+
+__device__ __forceinline__ uint32_t shk_pick_word(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t p) {
+  return (a & (0u - (uint32_t)(p == 0))) | (b & (0u - (uint32_t)(p == 1))) | (c & (0u - (uint32_t)(p == 2))) | (d & (0u - (uint32_t)(p == 3)));
+}
+// shk_roll_round for a staged read (`pk` = its first unit; no 'N', so no restart: one (sub)read, fill = min(i, k)).
+// A round's 16 incoming bases are one 32-bit word of the unit held in s.i0_; the 16 that leave start 2 * (i - k) bits
+// into the read's stream: two neighbouring words, taken from s.o0_ = 16 bytes fetched (at any 4-byte offset) every third
+// round. Same register budget as the text form with one quad per stream.
+template <typename Emit>
+__device__ __forceinline__ bool shk_roll_round_pk(const ShkRollTabs *T, const ShkQuad *pk, ShkRollState &s, uint32_t k, uint64_t mask, Emit emit) {
+  if (s.i >= s.len) return false;
+  const uint32_t i0 = s.i, ph = (i0 >> 4) & 3;
+  if (ph == 0) s.i0_ = pk[i0 >> 6];
+  const uint32_t zin = shk_pick_word(s.i0_.x, s.i0_.y, s.i0_.z, s.i0_.w, ph);
+  uint64_t fh = s.fh, rh = s.rh;
+  if (i0 >= k) {
+    const uint32_t n = (i0 >> 4) - ((k + 15) >> 4);         // rounds of this form so far (< 4096)
+    const uint32_t n3 = n - 3 * ((n * 0xAAABu) >> 17);      // n mod 3
+    const uint32_t ob = 2 * (i0 - k);                       // bit at which the leaving bases start
+    if (n3 == 0) __builtin_memcpy(&s.o0_, reinterpret_cast<const uint8_t *>(pk) + 4 * (uint64_t)(ob >> 5), 16);
+    const uint32_t a = shk_pick_word(s.o0_.x, s.o0_.y, s.o0_.z, 0, n3), b = shk_pick_word(s.o0_.y, s.o0_.z, s.o0_.w, 0, n3);
+    const uint32_t zout = (uint32_t)((((uint64_t)b << 32) | a) >> (ob & 31));
+    const auto step = [&](int j, bool whole) {
+      const uint32_t oi = (j < 2 ? zin << (4 - 2 * j) : zin >> (2 * j - 4)) & 0x30u;       // code times sizeof(ShkRollRow)
+      const uint32_t oo = (j < 2 ? zout << (4 - 2 * j) : zout >> (2 * j - 4)) & 0x30u;
+      const ShkRollRow ri = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->in4) + oi);
+      const ShkRollRow ro = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->out4) + oo);
+      fh = shk_rol1(fh) ^ ri.f ^ ro.f;
+      rh = shk_ror1(rh) ^ ri.r ^ ro.r;
+      if (whole || i0 + j < s.len) emit(j, (fh < rh ? fh : rh) & mask);
+    };
+    if (i0 + SHK_ROLL_STEPS <= s.len) {
+#pragma unroll
+      for (int j = 0; j < SHK_ROLL_STEPS; j++) step(j, true);
+    } else {
+#pragma unroll
+      for (int j = 0; j < SHK_ROLL_STEPS; j++) step(j, false);
+    }
+  } else if (i0 + SHK_ROLL_STEPS < k) {
+    // inside the first window: sixteen bases go in, nothing comes out
+#pragma unroll
+    for (int j = 0; j < SHK_ROLL_STEPS; j++) {
+      const uint32_t oi = (j < 2 ? zin << (4 - 2 * j) : zin >> (2 * j - 4)) & 0x30u;
+      const ShkRollRow ri = *reinterpret_cast<const ShkRollRow *>(reinterpret_cast<const uint8_t *>(T->in4) + oi);
+      fh = shk_rol1(fh) ^ ri.f;
+      rh = shk_ror1(rh) ^ ri.r;
+    }
+  } else {
+    // the round in which the first window fills: the bases that leave in it are among the read's first sixteen
+    const uint32_t z0 = (i0 >> 6) == 0 ? s.i0_.x : pk[0].x;
+#pragma unroll
+    for (int j = 0; j < SHK_ROLL_STEPS; j++) {
+      const uint32_t idx = i0 + j;
+      const ShkRollRow ri = T->in4[(zin >> (2 * j)) & 3u];
+      uint64_t f = shk_rol1(fh) ^ ri.f, r = shk_ror1(rh) ^ ri.r;
+      if (idx >= k) {
+        const ShkRollRow ro = T->out4[(z0 >> (2 * (idx - k))) & 3u];
+        f ^= ro.f; r ^= ro.r;
+      }
+      fh = f; rh = r;
+      if (idx + 1 >= k && idx < s.len) emit(j, (f < r ? f : r) & mask);
+    }
+  }
+  s.fh = fh; s.rh = rh;
+  s.i = i0 + SHK_ROLL_STEPS < s.len ? i0 + SHK_ROLL_STEPS : s.len;
+  return true;
+}
+
 // first-level digit of a key (masked to hb bits). The context's first quotient is a multiple of the region size, so
 // region = ((key >> 8) - q_lo) >> 8 = (key >> 16) - (q_lo >> 8), and its low 32 bits are all there is (regions < 2^25)
 __device__ __forceinline__ uint32_t shk_roll_digit(uint64_t key, const ShkRollArgs &A) {
@@ -222,8 +362,13 @@ __global__ void __launch_bounds__(THREADS) k_roll_hist(ShkRollArgs A) {
     if (en - st < A.k) continue;
     ShkRollState s;
     s.st = st; s.len = (uint32_t)(en - st); s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
-    while (shk_roll_round<4>(&T, A.text, A.safe_end, s, A.k, mask, [&](int, uint64_t key) {
-      atomicAdd(&lh[(((uint32_t)(key >> 16) - qlo16) >> A.hist_shift) & (P - 1)], 1u); })) {}
+    const auto count = [&](int, uint64_t key) { atomicAdd(&lh[(((uint32_t)(key >> 16) - qlo16) >> A.hist_shift) & (P - 1)], 1u); };
+    if (A.pk && !(A.pk_flag[r] >> 31)) {
+      const ShkQuad *up = A.pk + A.pk_base[r];
+      while (shk_roll_round_pk(&T, up, s, A.k, mask, count)) {}
+    } else {
+      while (shk_roll_round<4>(&T, A.text, A.safe_end, s, A.k, mask, count)) {}
+    }
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < P; d += blockDim.x)
@@ -265,6 +410,7 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
       if (en - st <= 65535 && en - st >= A.k) {
         s.st = st; s.len = (uint32_t)(en - st); s.i = 0; s.fill = 0; s.fh = 0; s.rh = 0;
         tag = (uint64_t)(A.chunk_first + A.rd_chunk[r] * A.chunk_mul) << A.hb;
+        if (A.pk && !(A.pk_flag[r] >> 31)) s.st = A.pk_base[r] | (1ULL << 63);     // staged: its first unit instead of its text offset
         have = true;
       }
       r += stride;
@@ -275,11 +421,13 @@ __global__ void __launch_bounds__(THREADS) k_roll_scatter(ShkRollArgs A) {
     uint64_t w[SHK_ROLL_STEPS];
     uint32_t vm = 0;               // steps that completed a k-mer
     if (have) {
-      have = shk_roll_round<NQ>(&T, A.text, A.safe_end, s, A.k, mask, [&](int j, uint64_t key) {
+      const auto keep = [&](int j, uint64_t key) {
         w[j] = key | tag;
         atomicAdd(&lh[shk_roll_digit(key, A)], 1u);
         vm |= 1u << j;
-      });
+      };
+      have = (s.st >> 63) ? shk_roll_round_pk(&T, A.pk + (s.st & ~(1ULL << 63)), s, A.k, mask, keep)
+                          : shk_roll_round<NQ>(&T, A.text, A.safe_end, s, A.k, mask, keep);
       if (have && s.i >= s.len) have = false;
     }
     if (have || r < nreads) any_left = 1;

@@ -28,12 +28,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_ROLL_HIST, KP_ROLL_SCATTER, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_ROLL_HIST, KP_ROLL_SCATTER, KP_PACK, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc", "k_roll_hist", "k_roll_scatter"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc", "k_roll_hist", "k_roll_scatter", "k_pack_reads"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -412,6 +412,29 @@ static int hash_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   return SHK_OK;
 }
 
+// 2-bit staging of the batch's reads for the roll kernels (k_pack_reads), in `buf` = a buffer of max_batch_keys words that
+// nothing else uses until the roll kernels are done. Leaves A.pk null (text path for every read) when the buffer cannot
+// hold the batch's units or SHK_NO_PACK is set (measurement).
+static int pack_stage(shk_ctx *c, ShkRollArgs &A, uint64_t nreads, uint64_t text_bytes, uint64_t *buf) {
+  A.pk = nullptr; A.pk_base = nullptr; A.pk_flag = nullptr;
+  // units <= sum over reads of (len / 64 + 1) <= text_bytes / 64 + nreads when no two chunks overlap (k_pack_reads leaves
+  // the reads that do not fit on the text path); 16 bytes of slack for the roll kernels' 16-byte fetches
+  const uint64_t cap_units = c->cfg.max_batch_keys / 2 > 1 ? c->cfg.max_batch_keys / 2 - 1 : 0;
+  if (getenv("SHK_NO_PACK") || text_bytes / 64 + nreads + 1 > cap_units) return SHK_OK;
+  ProfScope ps(c, KP_PACK);
+  const uint32_t t = c->threads < 256 ? c->threads : 256;
+  { const uint64_t blocks = nreads / t + 1;
+    hipLaunchKernelGGL(k_pack_count, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(t), 0, c->stream, (const uint64_t *)c->d_rd_start,
+                       (const uint64_t *)c->d_rd_end, (const uint64_t *)(c->d_scalars + 0), c->cfg.k, c->d_nkeys); }
+  if (run_scan<uint32_t>(c, c->d_nkeys, nreads, nullptr, c->d_key_base)) return SHK_ERR_HIP;
+  { const uint64_t blocks = nreads * 4 / t + 1;
+    hipLaunchKernelGGL(k_pack_reads, dim3((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3(t), 0, c->stream, A.text, A.safe_end,
+                       (const uint64_t *)c->d_rd_start, (const uint64_t *)c->d_rd_end, (const uint64_t *)(c->d_scalars + 0),
+                       (const uint64_t *)c->d_key_base, c->d_nkeys, (ShkQuad *)buf, cap_units); }
+  A.pk = (const ShkQuad *)buf; A.pk_base = c->d_key_base; A.pk_flag = c->d_nkeys;
+  return SHK_OK;
+}
+
 // text + chunk table -> key words in d_words[0], partitioned by the first region digit; d_base[1] = bucket bases,
 // d_scalars[1] = #words (roll_kernels.hip). For contexts with at least two partition levels.
 static bool roll_path(const shk_ctx *c) { return c->nlevels >= 2 && (c->q_lo & (SHK_REGION - 1)) == 0 && !getenv("SHK_NO_ROLL"); }
@@ -435,6 +458,7 @@ static int roll_stage(shk_ctx *c, const void *text, int on_device, uint64_t text
   A.dig_shift = c->lv[0].shift; A.dig_bits = c->lv[0].bits;
   A.hist = two ? c->d_hist[1] : c->d_hist[0]; A.hist_shift = two ? c->lv[1].shift : c->lv[0].shift; A.hist_bits = two ? cb : c->lv[0].bits;
   A.cursor = c->d_cursor; A.out = c->d_words[0]; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
+  { int rc = pack_stage(c, A, nreads, text_bytes, c->d_words[1]); if (rc) return rc; }     // (d_words[1]: the partition's other buffer, idle until its second level)
   { ProfScope ps(c, KP_ROLL_HIST);
     if (two && c->threads >= 512) {
       const uint64_t blocks = nreads / 512 + 1;
@@ -1436,6 +1460,13 @@ extern "C" int shk_prepare_chunks(shk_ctx *c, const void *text, int text_on_devi
   return SHK_OK;
 }
 
+extern "C" int shk_prepare_reserve(shk_ctx *c) {
+  if (!c || c->cfg.num_shards > 1) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  if (!c->front) { int rc = front_init(c); if (rc) { front_destroy(c); return rc; } }
+  return SHK_OK;
+}
+
 extern "C" int shk_count_prepared(shk_ctx *c, shk_batch_stats *stats) {
   if (!c || !c->front || c->front->count == 0) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
@@ -1614,7 +1645,6 @@ extern "C" int shk_hash_route_chunks(shk_ctx *c, const void *text, int text_on_d
   const uint32_t nbins = 1u << db, per_owner = nbins / nshards;
   uint64_t *hist = c->d_block_sums;            // scratch: nbins <= 1024 words each
   uint64_t *cursor = c->d_block_sums + 4096;
-  HIPCHK(hipMemsetAsync(hist, 0, nbins * 8, c->stream));
   ShkRollArgs A;
   A.text = dtext; A.safe_end = (text_bytes + 15) & ~15ULL;
   A.rd_start = c->d_rd_start; A.rd_end = c->d_rd_end; A.nreads_p = c->d_scalars + 0; A.rd_chunk = c->d_rd_chunk;
@@ -1623,6 +1653,9 @@ extern "C" int shk_hash_route_chunks(shk_ctx *c, const void *text, int text_on_d
   A.dig_shift = rb - db; A.dig_bits = db;
   A.hist_shift = A.dig_shift; A.hist_bits = db;
   A.hist = hist; A.cursor = cursor; A.out = send; A.cap = c->cfg.max_batch_keys; A.err = c->d_err;
+  rc = pack_stage(c, A, nreads, text_bytes, c->d_words[0]);      // (d_words[0]: filled by shk_stage_words, after this call)
+  if (rc) return finish(c, rc);
+  HIPCHK(hipMemsetAsync(hist, 0, nbins * 8, c->stream));     // (behind pack_stage, whose scan uses the head of d_block_sums too)
   { ProfScope ps(c, KP_ROLL_HIST);
     if (c->threads >= 512) {
       const uint64_t blocks = nreads / 256 + 1;

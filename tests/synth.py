@@ -15,8 +15,9 @@ def make_genome(G, seed):
 
 
 def make_fastq(genome, nreads, L, err, seed, n_frac=0.001, short_frac=0.0, lower_frac=0.0,
-               name_prefix="r", plus_repeats_name=False):
-    """returns bytes of a FASTQ file"""
+               name_prefix="r", plus_repeats_name=False, iupac_frac=0.0):
+    """returns bytes of a FASTQ file. iupac_frac: share of reads with a few bytes that are neither a base nor 'N' (IUPAC
+    codes, '.', '-', 'n'): seed 0 on the forward strand, seedTab[byte & 7] on the complement strand, no restart"""
     rng = np.random.default_rng(seed)
     G = len(genome)
     out = []
@@ -39,6 +40,10 @@ def make_fastq(genome, nreads, L, err, seed, n_frac=0.001, short_frac=0.0, lower
             s[a:b] = ord("N")
         if lower_frac and rng.random() < lower_frac:
             s = np.frombuffer(bytes(s).lower(), dtype=np.uint8)
+        if iupac_frac and rng.random() < iupac_frac:
+            s = s.copy()
+            for p in rng.integers(0, ln, size=int(rng.integers(1, 4))):
+                s[p] = b"RYKMSWBDHVn.-*U"[int(rng.integers(0, 15))]
         name = f"@{name_prefix}{i}".encode()
         qual = b"I" * ln
         plus = b"+" + (name[1:] if plus_repeats_name else b"")

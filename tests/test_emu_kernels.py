@@ -523,3 +523,17 @@ def test_prepared_batches_give_the_same_filter(shk):
     assert ctx.blocks() == q.blocks() and ctx.header() == oracle_header(q)
     ctx.close()
     q.free()
+
+
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_roll_kernels_key_multiset_over_k_and_read_shapes(shk, monkeypatch, pack):
+    """roll_cases.run on the emulator build; pack = 0: every read on the text path (SHK_NO_PACK)"""
+    import roll_cases
+    if pack == "0":
+        monkeypatch.setenv("SHK_NO_PACK", "1")
+
+    def mk(**kw):
+        ctx = _ctx(shk, **kw)
+        ctx.read_words = lambda dp, n: list((C.c_uint64 * max(n, 1)).from_address(dp)[:n])
+        return ctx
+    roll_cases.run(mk, pack == "1")

@@ -1139,3 +1139,22 @@ def test_qb34_whole_filter_context_fits_one_gpu():
     removed = ctx.denoise()
     assert 0 < removed < nd and ctx.totals().ndistinct == nd - removed
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pack", [True, False])
+def test_roll_kernels_key_multiset_over_k_and_read_shapes(monkeypatch, pack):
+    """roll_cases.run on the GPU: the roll kernels' (2-bit staged and text) and the wave-per-read kernel's key streams over
+    k = 5..129, read lengths around the 16-base rounds and 64-base units, lower case, 'N' and IUPAC bytes"""
+    import torch
+    import roll_cases
+    from shk import dist as shkdist
+    if not pack:
+        monkeypatch.setenv("SHK_NO_PACK", "1")
+    dev = torch.device("cuda", 0)
+
+    def mk(**kw):
+        ctx = _ctx(**kw)
+        ctx.read_words = lambda dp, n: [x & 0xFFFFFFFFFFFFFFFF for x in shkdist.wrap_words(dp, n, dev).cpu().tolist()]
+        return ctx
+    roll_cases.run(mk, pack)

@@ -328,3 +328,27 @@ def test_contiger_roll_sequence_equals_scratch_hashes():
             fh, rh = R.nthash_roll(ord("T"), x, k, fh, rh)            # NTPC64('T', x, K, current_kmer_hash, current_kmer_RC_hash)
             cur = fix + bytes([x])
             assert (fh, rh) == R.nthash(cur, k)
+
+
+@needs_ref
+def test_oracle_vs_reference_reads_with_bytes_that_are_no_base():
+    """reads_to_kmers over reads holding IUPAC codes and other bytes: a byte that is no base hashes as seed 0 on the
+    forward strand but as seedTab[byte & 7] on the complement strand (nthash.hpp:15,299: not 0 for Y K S W D ...), only
+    an upper-case 'N' restarts the window (CQF_mt.h:672-676). Oracle and compiled reference insert the same keys."""
+    R = cqflibs.ref()
+    rnd = random.Random(31)
+    for k in (21, 47):
+        recs = []
+        for i in range(60):
+            L = rnd.randrange(k, 220)
+            s = [rnd.choice("ACGT") for _ in range(L)]
+            for _ in range(rnd.choice([1, 2, 5])):
+                s[rnd.randrange(L)] = rnd.choice("NnRYKMSWBDHVacgt.-*U")
+            recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join(s), "I" * L))
+        fq = "".join(recs).encode()
+        o, r = O.new(14), R.new(14)
+        o.reads_to_kmers(fq, k), r.reads_to_kmers(fq, k)
+        assert o.blocks() == r.blocks() and o.nelts() == r.nelts() > 0
+        keys = O.chunk_keys(fq, k, 22)
+        assert len(keys) == o.nelts()
+        o.free(), r.free()

@@ -41,7 +41,8 @@ def main():
         while nreads > 64 and 1.3 * min(G, nreads * (L - k + 1)) + nreads * (L - k + 1) * (1 - (1 - err) ** k) > 0.9 * (1 << qb):
             nreads = nreads * 3 // 4
         fq = synth.make_fastq(synth.make_genome(G, rnd.randrange(1 << 30)), nreads, L, err, seed=rnd.randrange(1 << 30),
-                              n_frac=rnd.choice([0.0, 0.02, 0.2]), short_frac=rnd.choice([0.0, 0.05]), lower_frac=rnd.choice([0.0, 0.05]))
+                              n_frac=rnd.choice([0.0, 0.02, 0.2]), short_frac=rnd.choice([0.0, 0.05]), lower_frac=rnd.choice([0.0, 0.05]),
+                              iupac_frac=rnd.choice([0.0, 0.0, 0.1]))
         per = max(1, nreads // rnd.choice([1, 3, 7, 20]))
         offs, lens = chunks_by_records(fq, per)
         nd = rnd.choice([0, 1, 2, 3, 6])
