@@ -495,7 +495,7 @@ def test_randomised_configurations_on_the_emulator(shk, flow):
     env = dict(os.environ, MASTER_PORT=str(29800 + os.getpid() % 150))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
-    assert "12 cases, 0 mismatches" in r.stdout
+    assert "fuzz: 12 cases (" in r.stdout and ", 0 mismatches" in r.stdout, r.stdout[-500:]
 
 
 def test_prepared_batches_give_the_same_filter(shk):
