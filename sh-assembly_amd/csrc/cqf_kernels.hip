@@ -33,7 +33,8 @@ struct ShkMergeArgs {
   const uint64_t *finA;         // [nregions+1] free pointer at each region start of A
   uint64_t *finB;               // same for B (write pass input; written by the single-launch rebuild)
   const uint32_t *words;        // 32-bit records sorted by region (written by the last partition level); null when there are none
-  const uint64_t *region_base;  // [nregions+1] offsets into words
+  const uint64_t *region_base;  // [nregions+1] offsets into words; with region_cap: [nregions] END offsets, region r starts at r * region_cap
+  uint32_t region_cap;          // 0, or the fixed capacity of a region's slot in `words` (ShkRpLevel::slot_cap)
   uint64_t nslots, xnslots, nblocks;
   uint64_t q_lo;
   uint32_t hb;
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
 
   // A region without old runs and without words has nothing to say: T = 0, no statistics, all lengths 0
   // (sparse tables -- the first batches of a build, big filters -- are mostly such regions)
-  if ((MODE == 0 || MODE == 3) && !old_any && !fatal && (!A.words || A.region_base[r] == A.region_base[r + 1])) {
+  if ((MODE == 0 || MODE == 3) && !old_any && !fatal && (!A.words || (A.region_cap ? A.region_base[r] == (uint64_t)r * A.region_cap : A.region_base[r] == A.region_base[r + 1]))) {
     if (tid < SHK_SUM_STRIDE) A.summary[(size_t)SHK_SUM_STRIDE * r + tid] = 0;
     if (MODE == 3 && tid < SHK_WAVE) reinterpret_cast<uint32_t *>(A.spill + (size_t)r * SHK_SPILL_STRIDE)[tid] = 0;
     if (FUSED) {
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // slot can hold, min with ~0, add 0. Four words per lane probe together; the loop condition is wave-uniform.
   uint32_t my_added = 0, my_added_b = 0;
   if (A.words && !fatal && !(A.ablate & 1)) {
-    const uint64_t kb = A.region_base[r], ke = A.region_base[r + 1];
+    const uint64_t kb = A.region_cap ? (uint64_t)r * A.region_cap : A.region_base[r], ke = A.region_cap ? A.region_base[r] : A.region_base[r + 1];
     const unsigned lane = shk_lane();
     const bool wh = A.want_hist != 0;
     bool corrupt = false, hfull = false;

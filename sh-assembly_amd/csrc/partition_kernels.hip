@@ -21,6 +21,10 @@ struct ShkRpLevel {
   uint64_t nslots;    // quotients this context owns
   uint32_t out32;     // 1 (last level): write 32-bit records (quotient in region << 8 | remainder) << SHK_CHUNK_BITS | chunk
   uint32_t ablate;    // diagnostics only (SHK_RP_ABLATE): 1 = no reservation atomics, all windows write the same few KB per digit (results invalid)
+  uint32_t slot_cap;  // last level only, 0 = off: bucket (region) i owns the fixed slot [i * slot_cap, (i + 1) * slot_cap) of the
+                      // output instead of an exact range from a histogram pass + scan (the keys are hash values: a
+                      // region's share of a batch is its mean +- a few sigma); `cursor` starts at the slots' first
+                      // positions and ends as the regions' END positions. A region that gets more raises SHK_E_SLOT_FULL
   uint32_t ng_log2;   // first level only: every digit's bucket is laid out as 2^ng_log2 sub-buckets, one per window group
                       // (window index mod 2^ng_log2), each with its own cursor, so that the windows of a batch do not all
                       // reserve from the same P addresses. Measured on 832 M keys: the scatter itself is unchanged (its
@@ -159,6 +163,12 @@ __global__ void k_rp_group_bases(const uint64_t *sub, uint32_t nd, uint32_t ng_l
 #define SHK_RP_THREADS 512
 #define SHK_RP_KPT (SHK_RP_TILE / SHK_RP_THREADS)
 // (TILE_LOG2, THREADS) = (12, 512) for all levels but the first of a context's own partition: (SHK_RP_TILE0_LOG2, 1024)
+// fixed-capacity region slots: cursor[i] = i * cap
+__global__ void k_rp_slot_cursors(uint64_t *cursor, uint64_t n, uint32_t cap) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cursor[i] = i * cap;
+}
+
 template <int TILE_LOG2, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
                                                         const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
@@ -211,6 +221,10 @@ __global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint
         lbase[d] = carry + ex;
         if (lv.ablate & 1) gbase[d] = cursor[((uint64_t)b * P + d) << lv.ng_log2] + (uint64_t)(blockIdx.x % 1024) * 24;
         else gbase[d] = v ? atomicAdd((unsigned long long *)&cursor[((((uint64_t)b * P) + d) << lv.ng_log2) | (blockIdx.x & ((1u << lv.ng_log2) - 1))], (unsigned long long)v) : 0;
+        if (lv.slot_cap && v && gbase[d] + v > ((uint64_t)b * P + d + 1) * lv.slot_cap) {
+          atomicOr(err, SHK_E_SLOT_FULL);
+          gbase[d] = ~0ULL;              // (nothing of this run is written)
+        }
       }
       carry += tot;
     }
@@ -232,7 +246,7 @@ __global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint
         if (q >= lv.nslots) atomicOr(err, SHK_E_CORRUPT);
         const uint32_t rec = ((((uint32_t)q & (SHK_REGION - 1)) << 8 | (uint32_t)(key & 0xff)) << SHK_CHUNK_BITS) |
                              ((uint32_t)(x >> lv.hb) & (SHK_MAX_CHUNKS - 1));
-        reinterpret_cast<uint32_t *>(out)[gbase[d] + (i - lbase[d])] = rec;
+        if (gbase[d] != ~0ULL) reinterpret_cast<uint32_t *>(out)[gbase[d] + (i - lbase[d])] = rec;
       } else {
         out[gbase[d] + (i - lbase[d])] = x;
       }

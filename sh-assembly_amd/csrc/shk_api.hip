@@ -28,12 +28,12 @@
 
 enum {
   KP_COUNT_LINES, KP_SCAN_CHUNKS, KP_EMIT_READS, KP_COUNT_KEYS, KP_HASH, KP_SCAN, KP_RP_PREP, KP_RP_HIST,
-  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_ROLL_HIST, KP_ROLL_SCATTER, KP_PACK, KP_N
+  KP_RP_SCATTER, KP_MERGE_SUM, KP_REGION_SCAN, KP_MERGE_WRITE, KP_MERGE_SINGLE, KP_MERGE_SPILL, KP_PLACE, KP_MARKS, KP_LOOKUP, KP_WALK, KP_UG_WALK, KP_UG_FINISH, KP_MERGE_FUSED, KP_MERGE_SAMPLE, KP_MISC, KP_ROLL_HIST, KP_ROLL_SCATTER, KP_PACK, KP_RP_SLOTS, KP_N
 };
 static const char *kp_names[KP_N] = {
   "k_count_lines", "k_scan_chunks", "k_emit_reads", "k_count_keys", "k_hash_reads", "k_scan_*", "k_rp_prep",
   "k_rp_hist", "k_rp_scatter", "k_region_merge<summary>", "k_region_scan", "k_region_merge<write>", "k_region_merge<single>",
-  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc", "k_roll_hist", "k_roll_scatter", "k_pack_reads"};
+  "k_region_merge<spill>", "k_region_place", "k_denoise_marks", "k_lookup", "k_extend_forward+k_select_seeds", "k_ug_walk", "k_ug_check/emit/median/links", "k_region_merge<fused>", "k_region_merge<sample>", "misc", "k_roll_hist", "k_roll_scatter", "k_pack_reads", "k_rp_slot_cursors"};
 
 struct PendingEvent { int id; hipEvent_t a, b; };
 
@@ -90,6 +90,10 @@ struct shk_ctx {
   uint64_t *h_chist;            // pinned
   uint32_t chist_n;             // entries of h_chist valid from the last summary (0 = none)
   uint32_t sample_stride;       // sampled statistics pass before a deNoise point: every n-th region (<= 1: off)
+  uint32_t region_cap;          // how the partitioned words lie: 0 = d_base[nlevels] holds exact offsets; else region r owns the slot
+                                // [r * region_cap, ...) and d_base[nlevels][r] is its END (ShkRpLevel::slot_cap)
+  uint32_t slot_overflows;      // consecutive batches whose slotted last level overflowed; at 2 the slots are switched off
+  int slots_off;
   uint32_t pt_lo, pt_split, pt_hi; int pt_valid; uint64_t pt_nprot;   // one-pass deNoise point in progress (shk_stage_point_*)
   const uint64_t *pt_words;     // its words (null: a round on its own, shk_stage_round_try)
   unsigned long long *d_counters;  // 4 counters + 32 hist bins
@@ -211,7 +215,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
       uint32_t bits = (left + (c->nlevels - l) - 1) / (c->nlevels - l);
       left -= bits;
       c->lv[l].shift = left; c->lv[l].bits = bits; c->lv[l].nbuckets = nb; c->lv[l].hb = cfg->hb; c->lv[l].q_lo = c->q_lo;
-      c->lv[l].nslots = c->nslots; c->lv[l].out32 = 0; c->lv[l].ablate = 0; c->lv[l].ng_log2 = 0;
+      c->lv[l].nslots = c->nslots; c->lv[l].out32 = 0; c->lv[l].ablate = 0; c->lv[l].ng_log2 = 0; c->lv[l].slot_cap = 0;
       nb <<= bits;
     }
     c->lv[c->nlevels - 1].out32 = 1;
@@ -263,6 +267,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   if (const char *mg = getenv("SHK_MERGE_GROUP")) { int v = atoi(mg); if (v == 64 || v == 128) c->merge_group = (uint32_t)v; }
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
   // the sampled location of a deNoise point needs enough regions for the sample to mean something
+  c->region_cap = 0; c->slot_overflows = 0; c->slots_off = getenv("SHK_NO_SLOTS") ? 1 : 0;
   c->sample_stride = 8;
   if (const char *e = getenv("SHK_SAMPLE_STRIDE")) c->sample_stride = (uint32_t)atoi(e);
   else if (c->nregions < (1u << 14)) c->sample_stride = 0;
@@ -513,36 +518,69 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
   const uint32_t nwin = (uint32_t)(nmax / SHK_RP_TILE + 1);
   const uint64_t *in = ext ? ext : c->d_words[src];
   int cur = ext ? 1 : src;   // the buffer `in` occupies (an external source leaves both free: write to d_words[0] first)
+  c->region_cap = 0;
   for (uint32_t l = first_level; l < c->nlevels; l++) {
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
-    { ProfScope ps(c, KP_RP_PREP);
-      hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb);
-      if (!(l == 0 && hist0_ready) && !(l == 1 && hist1_ready)) HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream)); }
-    if (!(l == 0 && hist0_ready) && !(l == 1 && hist1_ready)) { ProfScope ps(c, KP_RP_HIST);
-      const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
-      hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt); }
-    if (c->lv[l].ng_log2) {
-      // (first level only: nb = 1) sub-buckets in (digit, group) order; the next level's buckets are the digits
-      const uint32_t ng = c->lv[l].ng_log2;
-      if (run_scan<uint64_t>(c, c->d_hist[l], P << ng, nullptr, c->d_base_sub)) return SHK_ERR_HIP;
-      HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base_sub, (P << ng) * 8, hipMemcpyDeviceToDevice, c->stream));
-      ProfScope ps(c, KP_RP_PREP);
-      hipLaunchKernelGGL(k_rp_group_bases, dim3((uint32_t)(P / 256 + 1)), dim3(256), 0, c->stream, c->d_base_sub, (uint32_t)P, ng, c->d_base[l + 1]);
-    } else {
-      if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
-      HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
+    // Last level: fixed-capacity region slots instead of a histogram pass over the keys + scan, when the output buffer
+    // (max_batch_keys 8-byte words = twice as many 4-byte records) gives every region room for its mean share of this
+    // batch plus six sigma of a clumpy hash distribution (a true k-mer comes ~8 times per batch). A region that gets
+    // more (repeats: one k-mer a million times) raises SHK_E_SLOT_FULL and the level is redone the exact way; after two
+    // such batches in a row the context stops trying.
+    uint32_t cap = 0;
+    if (l + 1 == c->nlevels && l >= 1 && c->lv[l].out32 && !c->slots_off && !(l == 1 && hist1_ready)) {
+      uint64_t cp = 2 * c->cfg.max_batch_keys / (nb * P);
+      if (cp > (1u << 20)) cp = 1u << 20;
+      const double mean = (double)nmax / (double)(nb * P);
+      if (cp >= 64 && (double)cp >= mean + 6.0 * sqrt(8.0 * mean + 1.0) + 16.0) cap = (uint32_t)cp;
     }
-    { ProfScope ps(c, KP_RP_SCATTER);
+    { ProfScope ps(c, KP_RP_PREP);
+      hipLaunchKernelGGL(k_rp_tile_first, dim3(nwin / 256 + 1), dim3(256), 0, c->stream, c->d_base[l], (uint32_t)nb, n_p, c->d_tfb); }
+    for (;;) {
       ShkRpLevel lvl = c->lv[l];
 #ifdef SHK_DIAGNOSTICS   // timing ablations give INVALID results: compiled into diagnostic builds only (make DIAG=1)
       if (const char *e = getenv("SHK_RP_ABLATE")) lvl.ablate = (uint32_t)atoi(e);
 #endif
-      if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
-        hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
-                           c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err);
-      else
-        hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
-                           c->d_base[l], c->d_tfb, lvl, c->d_cursor, c->d_err); }
+      uint64_t *cursor = c->d_cursor;
+      if (cap) {
+        ProfScope ps(c, KP_RP_SLOTS);
+        cursor = c->d_base[l + 1];           // (ends up as the regions' end positions)
+        lvl.slot_cap = cap;
+        hipLaunchKernelGGL(k_rp_slot_cursors, dim3((uint32_t)((nb * P) / 256 + 1 < 4096 ? (nb * P) / 256 + 1 : 4096)), dim3(256), 0, c->stream, cursor, nb * P, cap);
+      } else {
+        const bool ready = (l == 0 && hist0_ready) || (l == 1 && hist1_ready);
+        if (!ready) {
+          HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream));
+          ProfScope ps(c, KP_RP_HIST);
+          const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
+          hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt);
+        }
+        if (c->lv[l].ng_log2) {
+          // (first level only: nb = 1) sub-buckets in (digit, group) order; the next level's buckets are the digits
+          const uint32_t ng = c->lv[l].ng_log2;
+          if (run_scan<uint64_t>(c, c->d_hist[l], P << ng, nullptr, c->d_base_sub)) return SHK_ERR_HIP;
+          HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base_sub, (P << ng) * 8, hipMemcpyDeviceToDevice, c->stream));
+          ProfScope ps(c, KP_RP_PREP);
+          hipLaunchKernelGGL(k_rp_group_bases, dim3((uint32_t)(P / 256 + 1)), dim3(256), 0, c->stream, c->d_base_sub, (uint32_t)P, ng, c->d_base[l + 1]);
+        } else {
+          if (run_scan<uint64_t>(c, c->d_hist[l], nb * P, nullptr, c->d_base[l + 1])) return SHK_ERR_HIP;
+          HIPCHK(hipMemcpyAsync(c->d_cursor, c->d_base[l + 1], nb * P * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+      }
+      { ProfScope ps(c, KP_RP_SCATTER);
+        if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
+          hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
+                             c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, cursor, c->d_err);
+        else
+          hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
+                             c->d_base[l], c->d_tfb, lvl, cursor, c->d_err); }
+      if (!cap) break;
+      uint32_t bits = 0;
+      if (fetch_err(c, &bits)) return SHK_ERR_HIP;
+      if (bits & ~SHK_E_SLOT_FULL) return map_err_bits(bits & ~SHK_E_SLOT_FULL);
+      if (!bits) { c->region_cap = cap; c->slot_overflows = 0; break; }
+      if (++c->slot_overflows >= 2) c->slots_off = 1;
+      cap = 0;                               // a region overflowed its slot: the same level again with exact bases
+    }
     cur ^= 1;
     in = c->d_words[cur];
   }
@@ -583,7 +621,7 @@ static void fill_args(shk_ctx *c, ShkMergeArgs *A, const uint64_t *words, uint32
   A->want_hist = want_hist;
   A->tabA = c->tab[c->cur]; A->tabB = c->tab[c->cur ^ 1];
   A->finA = c->fin[c->cur]; A->finB = c->fin[c->cur ^ 1];
-  A->words = reinterpret_cast<const uint32_t *>(words); A->region_base = c->d_base[c->nlevels];
+  A->words = reinterpret_cast<const uint32_t *>(words); A->region_base = c->d_base[c->nlevels]; A->region_cap = c->region_cap;
   A->nslots = c->nslots; A->xnslots = c->xnslots; A->nblocks = c->nblocks; A->q_lo = c->q_lo; A->hb = c->cfg.hb;
   A->chunk_lo = lo; A->chunk_hi = hi; A->hist_base = hbase; A->hist_shift = hshift; A->denoise = denoise;
   A->ablate = 0;
@@ -1305,7 +1343,8 @@ extern "C" int shk_count_chunks(shk_ctx *c, const void *text, int text_on_device
 // (host synchronisations included) in a helper thread, so the caller's thread is free to drive the rebuild.
 struct ShkFrontSlot {
   uint64_t *words = nullptr;    // the buffer the last partition level writes into (and the roll kernels, two levels earlier)
-  uint64_t *base = nullptr;     // region bases of that batch
+  uint64_t *base = nullptr;     // region bases of that batch (region ENDS when cap != 0)
+  uint32_t cap = 0;             // shk_ctx::region_cap of that batch
   std::thread th;
   bool busy = false;
   int rc = 0, dst = 0;
@@ -1423,7 +1462,7 @@ static void front_run(shk_ctx *c, ShkFrontSlot *S, const void *text, int on_devi
     S->nwords = f->h_pinned[42];
     int dst = 0;
     rc = roll ? partition_stage(f, 0, S->nwords, &dst, nullptr, false, 1, h1) : partition_stage(f, 0, S->nwords, &dst, nullptr, true);
-    S->dst = dst;
+    S->dst = dst; S->cap = f->region_cap;
     if (!rc) {
       if (fetch_err(f, &bits)) rc = SHK_ERR_HIP;          // (synchronises the shadow's stream: the batch is ready)
       else if (bits) rc = map_err_bits(bits);
@@ -1489,9 +1528,10 @@ extern "C" int shk_count_prepared(shk_ctx *c, shk_batch_stats *stats) {
     } }
   if (S->rc) return S->rc;
   uint64_t *saved = c->d_base[c->nlevels];
-  c->d_base[c->nlevels] = S->base;
+  const uint32_t saved_cap = c->region_cap;
+  c->d_base[c->nlevels] = S->base; c->region_cap = S->cap;
   int rc = merge_stage(c, S->words, S->nchunks, S->nwords, &st);
-  c->d_base[c->nlevels] = saved;
+  c->d_base[c->nlevels] = saved; c->region_cap = saved_cap;
   if (stats) *stats = st;
   return finish(c, rc);
 }
@@ -1580,7 +1620,7 @@ extern "C" int shk_route_words(shk_ctx *c, uint64_t nwords, uint32_t nshards, ui
   // one partition level over the WHOLE filter's regions: digit = owner
   ShkRpLevel lv;
   lv.shift = (c->cfg.qb - SHK_REGION_LOG2) - lg; lv.bits = lg; lv.nbuckets = 1; lv.hb = c->cfg.hb; lv.q_lo = 0;
-  lv.nslots = ~0ULL; lv.out32 = 0; lv.ablate = 0; lv.ng_log2 = 0;
+  lv.nslots = ~0ULL; lv.out32 = 0; lv.ablate = 0; lv.ng_log2 = 0; lv.slot_cap = 0;
   c->h_pinned[43] = nwords;
   HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
   const uint64_t *n_p = c->d_scalars + 1;

@@ -40,6 +40,7 @@
 #define SHK_E_RUN_TOO_LONG (1u << 7)
 #define SHK_E_LOOKBACK     (1u << 8)   // single-launch rebuild gave up waiting for a predecessor (host falls back)
 #define SHK_E_FUSED        (1u << 9)   // the one-pass deNoise point met a region it does not handle (host takes the three-pass path)
+#define SHK_E_SLOT_FULL    (1u << 10)  // last partition level with fixed-capacity region slots: a region got more words (host redoes the level with exact bases)
 
 __device__ __forceinline__ unsigned shk_lane() { return threadIdx.x & (SHK_WAVE - 1); }
 __device__ __forceinline__ unsigned shk_wave() { return threadIdx.x / SHK_WAVE; }

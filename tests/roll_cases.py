@@ -3,6 +3,7 @@ import ctypes as C
 import random
 
 import cqflibs
+import synth
 from fastq_util import chunks_by_records
 
 
@@ -54,3 +55,41 @@ def run(mk_ctx, pack):
             dp2, nw2 = ctx.hash_chunks(fq, offs, lens)
             assert ctx.read_words(dp2, nw2) == exp, k
         ctx.close()
+
+
+def run_slots(mk_ctx):
+    """the last partition level gives every region a fixed-capacity slot instead of counting first (k_rp_slot_cursors, no
+    k_rp_hist for that level); a region that gets more words than its slot holds (here: a batch of poly-A reads, one k-mer
+    thousands of times) raises SHK_E_SLOT_FULL inside the library and the level is redone with exact bases; after two such
+    batches in a row the context stops trying. Tables equal the oracle's throughout."""
+    k, qb = 21, 14
+    uni = synth.make_fastq(synth.make_genome(3000, 5), 250, 100, 0.005, seed=8, n_frac=0.02)
+    poly = "".join("@p%d\n%s\n+\n%s\n" % (i, "A" * 100, "I" * 100) for i in range(60)).encode()
+    ctx = mk_ctx(qb=qb, k=k, max_batch_bytes=1 << 20, max_batch_keys=1 << 16, max_level_bits=2)
+    ctx.profile(True)
+    O = cqflibs.oracle()
+    q = O.new(qb)
+
+    def batch(fq, per):
+        offs, lens = chunks_by_records(fq, per)
+        ctx.profile_reset()
+        ctx.count_chunks(fq, offs, lens)
+        q.reads_to_kmers(fq, k)
+        assert ctx.blocks() == q.blocks()
+        return ctx.profile_get()
+
+    # three levels of 2 bits: the roll kernels' histogram pass counts the first two, the last one has slots of 2048 for
+    # 64 regions x ~310 words: no counting pass over the keys at all
+    p = batch(uni, 50)
+    assert p["k_rp_slot_cursors"][0] == 1 and "k_rp_hist" not in p
+    p = batch(poly, 20)                # 4800 times one key: its region overflows, the level runs again the exact way
+    assert p["k_rp_slot_cursors"][0] == 1 and p["k_rp_hist"][0] == 1
+    p = batch(uni, 50)                 # one overflow does not switch the slots off
+    assert p["k_rp_slot_cursors"][0] == 1 and "k_rp_hist" not in p
+    batch(poly, 20)
+    batch(poly, 20)                    # the second overflow in a row does: counting passes from here on
+    p = batch(uni, 50)
+    assert "k_rp_slot_cursors" not in p and p["k_rp_hist"][0] == 1
+    assert (ctx.totals().nelts, ctx.totals().ndistinct) == (q.nelts(), q.ndistinct())
+    ctx.close()
+    q.free()

@@ -537,3 +537,9 @@ def test_roll_kernels_key_multiset_over_k_and_read_shapes(shk, monkeypatch, pack
         ctx.read_words = lambda dp, n: list((C.c_uint64 * max(n, 1)).from_address(dp)[:n])
         return ctx
     roll_cases.run(mk, pack == "1")
+
+
+def test_last_partition_level_with_region_slots_and_its_exact_fallback(shk):
+    """roll_cases.run_slots on the emulator build"""
+    import roll_cases
+    roll_cases.run_slots(lambda **kw: _ctx(shk, **kw))

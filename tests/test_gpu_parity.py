@@ -1158,3 +1158,11 @@ def test_roll_kernels_key_multiset_over_k_and_read_shapes(monkeypatch, pack):
         ctx.read_words = lambda dp, n: [x & 0xFFFFFFFFFFFFFFFF for x in shkdist.wrap_words(dp, n, dev).cpu().tolist()]
         return ctx
     roll_cases.run(mk, pack)
+
+
+@pytest.mark.gpu
+def test_last_partition_level_with_region_slots_and_its_exact_fallback():
+    """roll_cases.run_slots on the GPU: fixed-capacity region slots at the last partition level, the exact fallback when a
+    region overflows its slot, and the switch-off after two overflowing batches in a row"""
+    import roll_cases
+    roll_cases.run_slots(_ctx)
