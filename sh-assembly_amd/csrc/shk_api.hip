@@ -268,7 +268,10 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
   // the sampled location of a deNoise point needs enough regions for the sample to mean something
   c->region_cap = 0; c->slot_overflows = 0; c->slots_off = getenv("SHK_NO_SLOTS") ? 1 : 0;
-  c->sample_stride = 8;
+  // every 8th region; every 16th from 2^20 regions on (qb >= 28): a wrong guess costs one more one-pass point (18 ms at
+  // qb 29), the sample 1.9 / 1.15 / 0.75 ms at stride 8 / 16 / 32; measured on the 12 points of the qb-29 bench: no wrong
+  // guess at 8 and 16, one at 32 (its chance grows with sqrt(stride) / sqrt(new keys per batch))
+  c->sample_stride = c->nregions >= (1u << 20) ? 16 : 8;
   if (const char *e = getenv("SHK_SAMPLE_STRIDE")) c->sample_stride = (uint32_t)atoi(e);
   else if (c->nregions < (1u << 14)) c->sample_stride = 0;
   if (dmalloc(&c->d_spill, (uint64_t)c->nregions * SHK_SPILL_STRIDE) || dmalloc(&c->d_over_list, (uint64_t)c->nregions + 1)) return SHK_ERR_HIP;
