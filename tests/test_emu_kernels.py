@@ -489,13 +489,13 @@ def test_randomised_configurations_on_the_emulator(shk, flow):
     """tools/fuzz_gpu.py on the CPU build of the kernels: random filter sizes, k, read mixes, chunking, batching, deNoise
     trigger / rounds / range length, sampled-guess strides and rebuild schemes; table bytes, header, counters, rounds and
     removed counts equal the oracle's t = 1 build in every case (the GPU suite runs hundreds of these per round)"""
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--emu", "--max-qb", "13", "--cases", "12", "--seed", "7"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "--emu", "--max-qb", "13", "--cases", "9", "--seed", "7"]
     if flow == "sharded":
         cmd += ["--sharded"]
     env = dict(os.environ, MASTER_PORT=str(29800 + os.getpid() % 150))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
-    assert "fuzz: 12 cases (" in r.stdout and ", 0 mismatches" in r.stdout, r.stdout[-500:]
+    assert "fuzz: 9 cases (" in r.stdout and ", 0 mismatches" in r.stdout, r.stdout[-500:]
 
 
 def test_prepared_batches_give_the_same_filter(shk):
