@@ -225,8 +225,10 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   constexpr unsigned IMG_BLOCKS = IMGB, IMG_SLOTS = IMGB * 64, IMG_BYTES = IMGB * SHK_BLOCK_BYTES;
   static_assert(IMGB <= SHK_WAVE, "one lane per image block in the rank/select step");
   __shared__ __attribute__((aligned(16))) uint32_t hkey[SHK_HCAP];   // tag << 12 | first chunk ; tag = local quotient << 8 | remainder
-  // occurrences in this batch; FUSED: 64 bits per key, low word = in the chunks <= split, high word = behind it (one LDS atomic)
-  __shared__ __attribute__((aligned(16))) uint32_t hcnt[FUSED ? 2 * SHK_HCAP : SHK_HCAP];
+  // occurrences in this batch; FUSED: two 16-bit counters per key, low = in the chunks <= split, high = behind it (one LDS
+  // atomic; a region with 2^15 words or more in one batch leaves the one-pass point to the general path: SHK_E_FUSED).
+  // Two 32-bit counters per key cost the one-pass kernel 2 KB of LDS and with them one workgroup per CU
+  __shared__ __attribute__((aligned(16))) uint32_t hcnt[SHK_HCAP];
   __shared__ uint32_t s_added_b;
   __shared__ __attribute__((aligned(16))) uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
   __shared__ uint16_t qoff[SHK_REGION + 2];
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     {
       const uint4 e4 = make_uint4(SHK_EMPTY, SHK_EMPTY, SHK_EMPTY, SHK_EMPTY), z4 = make_uint4(0, 0, 0, 0);
       for (uint32_t i = tid; i < SHK_HCAP / 4; i += ngrp) reinterpret_cast<uint4 *>(hkey)[i] = e4;
-      for (uint32_t i = tid; i < (FUSED ? 2 * SHK_HCAP : SHK_HCAP) / 4; i += ngrp) reinterpret_cast<uint4 *>(hcnt)[i] = z4;
+      for (uint32_t i = tid; i < SHK_HCAP / 4; i += ngrp) reinterpret_cast<uint4 *>(hcnt)[i] = z4;
       for (uint32_t i = tid; i < SHK_REGION / 4; i += ngrp) reinterpret_cast<uint4 *>(qcnt)[i] = z4;
     }
     if (tid < SHK_HIST_BINS) lhist[tid] = 0;
@@ -325,6 +327,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     const bool wh = A.want_hist != 0;
     bool corrupt = false, hfull = false;
     const uint32_t nw = (uint32_t)(ke - kb);   // a region's share of one batch is far below 2^32 words
+    if (FUSED && ((ke - kb) >= 32768 || A.counted) && tid == 0) atomicOr(A.err, SHK_E_FUSED);   // (16-bit counters, bit 31 of a word = the "new key" flag)
     const uint32_t *wp = A.words + kb;
     for (uint32_t i0 = 0; i0 < nw; i0 += 4 * ngrp) {
       uint32_t wv[4];
@@ -374,10 +377,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
             if (ins) slist[base + (uint32_t)__popcll(mi & ((1ULL << lane) - 1))] = (uint16_t)h[u];
           }
           if (wh) atomicMin(match ? &hkey[h[u]] : &hidle[lane], match ? (want[u] | chk[u]) : 0xFFFFFFFFu);   // first chunk of the key
-          if (FUSED) {
-            const unsigned long long inc = match ? (bef[u] ? (unsigned long long)wgt[u] : (unsigned long long)wgt[u] << 32) : 0ULL;
-            atomicAdd(match ? reinterpret_cast<unsigned long long *>(hcnt) + h[u] : reinterpret_cast<unsigned long long *>(hidle) + lane, inc);
-          } else atomicAdd(match ? &hcnt[h[u]] : &hidle[lane], match ? wgt[u] : 0u);
+          atomicAdd(match ? &hcnt[h[u]] : &hidle[lane], match ? ((FUSED && !bef[u]) ? wgt[u] << 16 : wgt[u]) : 0u);
           pend[u] = pend[u] && !match;
           h[u] = pend[u] ? ((h[u] + 1) & (SHK_HCAP - 1)) : h[u];
         }
@@ -557,8 +557,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
           } else ohas = false;
         }
         if (take_new) {
-          { const unsigned long long c2 = reinterpret_cast<const unsigned long long *>(hcnt)[nh]; cb += (uint32_t)c2; ca = c2 >> 32; }
-          if (A.newchunks && !take_old) hcnt[2 * nh + 1] = 0x80000000u;   // a key the table has not seen: its first chunk is collected below (the counts are consumed)
+          { const uint32_t c2 = hcnt[nh]; cb += c2 & 0xFFFFu; ca = c2 >> 16; }
+          if (A.newchunks && !take_old) hcnt[nh] = 0x80000000u;   // a key the table has not seen: its first chunk is collected below (the counts are consumed)
           ni++;
           ncomp = NONE;
           if (ni < ne) { nh = nidx[ni]; nkey = hkey[nh]; ncomp = nkey >> SHK_CHUNK_BITS; }
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
     uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < nlist; i0 += SHK_WAVE) {     // nidx[0, nlist) = every hash slot in use
       const uint32_t h = i0 + tid < nlist ? nidx[i0 + tid] : 0;
-      const bool f = i0 + tid < nlist && (hcnt[FUSED ? 2 * h + 1 : h] >> 31);
+      const bool f = i0 + tid < nlist && (hcnt[h] >> 31);
       const unsigned long long m = __ballot(f);
       if (f) {
         const uint32_t at = base + (uint32_t)__popcll(m & ((1ULL << tid) - 1));

@@ -93,3 +93,27 @@ def run_slots(mk_ctx):
     assert (ctx.totals().nelts, ctx.totals().ndistinct) == (q.nelts(), q.ndistinct())
     ctx.close()
     q.free()
+
+
+def run_fused_point_with_a_crowded_region(mk_ctx):
+    """the one-pass deNoise point keeps two 16-bit counters per key; a region that receives 2^15 words or more in the
+    batch (poly-A reads: one k-mer 34,000 times) makes it hand the point to the general path (SHK_E_FUSED inside the
+    library). Rounds, removed counts and table bytes equal the oracle's t = 1 build either way."""
+    from fastq_util import oracle_t1, oracle_header
+    k, qb = 21, 14
+    uni = synth.make_fastq(synth.make_genome(2500, 15), 260, 100, 0.005, seed=18)
+    poly = "".join("@p%d\n%s\n+\n%s\n" % (i, "A" * 100, "I" * 100) for i in range(430)).encode()
+    for crowded in (False, True):
+        fq = uni + (poly if crowded else b"") + synth.make_fastq(synth.make_genome(2500, 16), 260, 100, 0.005, seed=19, name_prefix="s")
+        offs, lens = chunks_by_records(fq, 40)
+        q, orounds, oremoved = oracle_t1(fq, offs, lens, k, qb, 3500, 2, False, 1 << 20)
+        assert not q.full() and orounds >= 1
+        ctx = mk_ctx(qb=qb, k=k, trigger=3500, num_denoise=2, min_denoise_len=1 << 20, max_batch_bytes=1 << 21, max_batch_keys=1 << 17,
+                     max_level_bits=2)
+        ctx.profile(True)
+        st = ctx.count_chunks(fq, offs, lens)
+        assert (st["denoise_rounds"], st["removed"]) == (orounds, oremoved)
+        assert ctx.blocks() == q.blocks() and ctx.header() == oracle_header(q)
+        assert "k_region_merge<fused>" in ctx.profile_get()      # the one-pass point was tried
+        ctx.close()
+        q.free()

@@ -543,3 +543,10 @@ def test_last_partition_level_with_region_slots_and_its_exact_fallback(shk):
     """roll_cases.run_slots on the emulator build"""
     import roll_cases
     roll_cases.run_slots(lambda **kw: _ctx(shk, **kw))
+
+
+def test_one_pass_denoise_point_with_a_crowded_region(shk, monkeypatch):
+    """roll_cases.run_fused_point_with_a_crowded_region on the emulator build (sampled guess from every 2nd region)"""
+    import roll_cases
+    monkeypatch.setenv("SHK_SAMPLE_STRIDE", "2")
+    roll_cases.run_fused_point_with_a_crowded_region(lambda **kw: _ctx(shk, **kw))

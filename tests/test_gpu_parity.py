@@ -1166,3 +1166,12 @@ def test_last_partition_level_with_region_slots_and_its_exact_fallback():
     region overflows its slot, and the switch-off after two overflowing batches in a row"""
     import roll_cases
     roll_cases.run_slots(_ctx)
+
+
+@pytest.mark.gpu
+def test_one_pass_denoise_point_with_a_crowded_region(monkeypatch):
+    """roll_cases.run_fused_point_with_a_crowded_region on the GPU: a region with 2^15 words or more in the batch of a deNoise
+    point sends the one-pass point (16-bit counters) to the general path; same rounds, removed counts and bytes"""
+    import roll_cases
+    monkeypatch.setenv("SHK_SAMPLE_STRIDE", "2")
+    roll_cases.run_fused_point_with_a_crowded_region(_ctx)
