@@ -208,8 +208,8 @@ __device__ __forceinline__ void shk_store_image(const ShkMergeArgs &A, uint32_t 
 // (free pointers come from k_region_scan_*). MODE 3: summary that also spills the run lengths
 // and encodings for k_region_place. MODE 2: single launch -- the wave obtains its
 // free pointer by looking back at the regions before it (see k_region_merge docs below).
-#define SHK_STAGE_PER_LANE 40   // bytes of encoded run kept per lane between the length pass and placement
-#define SHK_STAGE_STRIDE 44     // lanes 11 dwords apart: byte i of every lane's area falls into a different LDS bank
+#define SHK_STAGE_PER_LANE 32   // bytes of encoded run kept per lane between the length pass and placement
+#define SHK_STAGE_STRIDE 36     // lanes 9 dwords apart: byte i of every lane's area falls into a different LDS bank
 #define SHK_LB_VALID 0x80000000u
 #define SHK_LB_INCL (1ULL << 63)
 
@@ -230,7 +230,11 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // Two 32-bit counters per key cost the one-pass kernel 2 KB of LDS and with them one workgroup per CU
   __shared__ __attribute__((aligned(16))) uint32_t hcnt[SHK_HCAP];
   __shared__ uint32_t s_added_b;
-  __shared__ __attribute__((aligned(16))) uint32_t qcnt[SHK_REGION]; // new entries per quotient, later the new run length
+  // new entries per quotient, later the new run length: 16 bits each (at most SHK_HCAP keys; a run has at most 256 entries
+  // of at most 11 slots), two to a word for the counting sort's atomics. LDS is what limits this kernel's workgroups per
+  // CU: the allocation granule is 1280 bytes, and at nine granules (11520 bytes) 14 of them fit instead of 12
+  __shared__ __attribute__((aligned(16))) uint16_t qcnt[SHK_REGION];
+  uint32_t *qcntw = reinterpret_cast<uint32_t *>(qcnt);
   __shared__ uint16_t qoff[SHK_REGION + 2];
   __shared__ uint16_t nidx[SHK_HCAP];   // hash slots grouped by quotient, sorted by remainder
   __shared__ __attribute__((aligned(8))) uint16_t orend[SHK_REGION];// slot (image relative) of the j-th old runend of the region
@@ -242,13 +246,15 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   __shared__ uint64_t orunw[IMG_BLOCKS];
   __shared__ uint32_t oorank[SHK_REGION_BLOCKS + 1];
   __shared__ uint32_t orrank[IMG_BLOCKS + 1];
-  __shared__ uint32_t lhist[SHK_HIST_BINS];
   __shared__ uint32_t s_fail, s_added, s_nlist;
   // one private word (pair) per lane: where the branch-free probe loop sends the lanes that have nothing to do, so that
   // their no-op atomics do not land on random banks next to the real ones (LDS bank conflicts were 18 % of this kernel's
   // cycles). The words live in `orend`, which is idle until the fold is over -- 512 bytes more would push the plain
   // kernel's LDS over an allocation step and cost it a workgroup per CU (measured: 12.6 -> 13.7 ms).
   uint32_t *hidle = reinterpret_cast<uint32_t *>(orend);
+  // the coarse histogram of the merge pass lives in `orunw`, which only the rank/select step in front of the join uses
+  static_assert(sizeof(uint64_t) * IMG_BLOCKS >= sizeof(uint32_t) * SHK_HIST_BINS, "lhist fits orunw");
+  uint32_t *lhist = reinterpret_cast<uint32_t *>(orunw);
 
   unsigned long long t_prev = A.dbg ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned tid = threadIdx.x;
@@ -303,9 +309,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       const uint4 e4 = make_uint4(SHK_EMPTY, SHK_EMPTY, SHK_EMPTY, SHK_EMPTY), z4 = make_uint4(0, 0, 0, 0);
       for (uint32_t i = tid; i < SHK_HCAP / 4; i += ngrp) reinterpret_cast<uint4 *>(hkey)[i] = e4;
       for (uint32_t i = tid; i < SHK_HCAP / 4; i += ngrp) reinterpret_cast<uint4 *>(hcnt)[i] = z4;
-      for (uint32_t i = tid; i < SHK_REGION / 4; i += ngrp) reinterpret_cast<uint4 *>(qcnt)[i] = z4;
+      for (uint32_t i = tid; i < SHK_REGION / 8; i += ngrp) reinterpret_cast<uint4 *>(qcnt)[i] = z4;
     }
-    if (tid < SHK_HIST_BINS) lhist[tid] = 0;
     if (tid < 2 * SHK_WAVE) hidle[tid] = 0;
     if (WRITE) {
       uint32_t *z = reinterpret_cast<uint32_t *>(nimg);
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   SHK_STAMP(2);   // old structure (rank/select) when this wave did it
   // ---- group the new entries by quotient (counting sort of hash slots), sort by remainder
   const uint32_t nlist = (A.ablate & 16) ? 0 : s_nlist;
-  for (uint32_t i = tid; i < nlist; i += nthr) atomicAdd(&qcnt[hkey[slist[i]] >> (SHK_CHUNK_BITS + 8)], 1u);
+  for (uint32_t i = tid; i < nlist; i += nthr) { const uint32_t q = hkey[slist[i]] >> (SHK_CHUNK_BITS + 8); atomicAdd(&qcntw[q >> 1], 1u << (16 * (q & 1))); }
   shk_wave_sync();
   constexpr uint32_t per = SHK_REGION / nthr;  // consecutive quotients per lane
   const uint32_t qa = tid * per;
@@ -464,7 +469,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   for (uint32_t i = tid; i < nlist; i += nthr) {
     const uint32_t h = slist[i];
     const uint32_t q = hkey[h] >> (SHK_CHUNK_BITS + 8);
-    const uint32_t pos = qoff[q] + (atomicSub(&qcnt[q], 1u) - 1);
+    const uint32_t pos = qoff[q] + (((atomicSub(&qcntw[q >> 1], 1u << (16 * (q & 1))) >> (16 * (q & 1))) & 0xFFFFu) - 1);
     nidx[pos] = (uint16_t)h;
   }
   shk_wave_sync();
@@ -482,6 +487,8 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
   // (each lane sorted only its own quotients' segments)
   __syncthreads();                       // join: the old structure is in place (the helper wave leaves here)
   if (s_fail & SHK_E_CORRUPT) fatal = true;
+  if (tid < SHK_HIST_BINS) lhist[tid] = 0;   // (orunw is free from here on)
+  shk_wave_sync();
 
   SHK_STAMP(3);   // counting sort + per-quotient sort
   // ---- one pass over the quotients: merge old run and new keys -> run length, statistics,
@@ -527,7 +534,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       const uint32_t eq = comp >> 8, rem = comp & 0xff;
       if (eq != curq) {                     // the previous quotient's run is complete
         if (len) {
-          qcnt[curq] = len;
+          qcnt[curq] = (uint16_t)len;
           ShkMPw m; m.a = (int)len; m.b = (int)(curq + len);
           mine = shk_mpw_compose(mine, m);
         }
@@ -643,7 +650,7 @@ __global__ void __launch_bounds__(SHK_MERGE_GROUP) k_region_merge(ShkMergeArgs A
       len += el;
     }
     if (len) {
-      qcnt[curq] = len;
+      qcnt[curq] = (uint16_t)len;
       ShkMPw m; m.a = (int)len; m.b = (int)(curq + len);
       mine = shk_mpw_compose(mine, m);
     }
