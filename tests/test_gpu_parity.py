@@ -952,7 +952,8 @@ def test_config4_one_shard_of_eight_human_sized(tmp_path):
         cnt, _ = ctx.lookup(uniq[pick].tolist(), mode=2)
         assert cnt == mult[pick].tolist()
         absent = [(me << (hb - 3)) | (int(x) & ((1 << (hb - 3)) - 1)) for x in torch.randint(0, 1 << 40, (20000,)).tolist()]
-        absent = [a for a in absent if a not in set(uniq[pick].tolist())]
+        picked = set(uniq[pick].tolist())
+        absent = [a for a in absent if a not in picked]
         cnt0, _ = ctx.lookup(absent[:5000], mode=2)
         present = set(uniq.tolist()) if uniq.numel() < 3_000_000 else None
         if present is not None:
