@@ -169,16 +169,16 @@ __global__ void k_rp_slot_cursors(uint64_t *cursor, uint64_t n, uint32_t cap) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cursor[i] = i * cap;
 }
 
-template <int TILE_LOG2, int THREADS>
+template <int TILE_LOG2, int THREADS, int PMAX = SHK_RP_MAXP>
 __global__ void __launch_bounds__(THREADS) k_rp_scatter(const uint64_t *in, uint64_t *out, const uint64_t *n_p,
                                                         const uint64_t *bucket_base, const uint32_t *tfb, ShkRpLevel lv,
                                                         uint64_t *cursor, uint32_t *err) {
   constexpr uint32_t SHK_RP_TILE_ = 1u << TILE_LOG2;
   constexpr int KPT_ = (int)(SHK_RP_TILE_ / THREADS);   // keys per thread (registers)
   static_assert(SHK_RP_TILE_ <= 65536, "a rank inside a digit takes 16 bits");
-  __shared__ uint32_t lh[SHK_RP_MAXP];      // digit counts (= next rank while counting)
-  __shared__ uint32_t lbase[SHK_RP_MAXP];   // local exclusive base of each digit
-  __shared__ uint64_t gbase[SHK_RP_MAXP];   // reserved global base of each digit
+  __shared__ uint32_t lh[PMAX];      // digit counts (= next rank while counting); PMAX >= 2^lv.bits (the host's choice)
+  __shared__ uint32_t lbase[PMAX];   // local exclusive base of each digit
+  __shared__ uint64_t gbase[PMAX];   // reserved global base of each digit
   __shared__ uint64_t stage[SHK_RP_TILE_];
   __shared__ uint32_t scratch[SHK_MAX_WAVES + 1];
   const uint64_t n = *n_p;
