@@ -167,7 +167,7 @@ def secondary_contiger(torch, shk, ctx, text, offs, lens, k):
     ext = st["extensions"]
     return {"what": "Contiger -s 2 -x 2 on the filter just built, seeds from one batch of reads (8 M), unitigs.fa written",
             "seeds": nseeds, "unitigs": st["unitigs"], "total_len": st["total_len"], "walk_wall_s": t_walk,
-            "walk_kernel_s": walk_ms / 1e3, "extended_bases": ext,
+            "walk_kernel_s": walk_ms / 1e3, "walk_rounds": st.get("rounds"), "extended_bases": ext,
             "bases_per_s_walk_kernel": ext / (walk_ms / 1e3) if walk_ms else None,
             "lookups_per_s_walk_kernel": 7 * ext / (walk_ms / 1e3) if walk_ms else None,
             "GBps_at_97B_per_lookup": 97 * 7 * ext / (walk_ms / 1e3) / 1e9 if walk_ms else None,
