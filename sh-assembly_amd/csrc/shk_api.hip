@@ -2780,25 +2780,54 @@ extern "C" int shk_unitig_set_write(shk_unitig_set *u, uint32_t k, const char *o
   hipFree(d_keep); hipFree(d_lens); hipFree(d_newid); hipFree(d_off); hipFree(d_bases); hipFree(d_cnt); hipFree(d_uoff); hipFree(d_ulen);
   hipFree(d_ul1); hipFree(d_med); hipFree(d_links); hipFree(m_lo); hipFree(m_hi); hipFree(m_v); hipFree(d_sums);
   if (rc) { fclose(fo); return finish(c, rc); }
-  // the records as the reference writes them (:606-626): ids 0-based in final numbering, successors then predecessors
-  std::string line;
-  for (uint64_t i = 0; i < nunits; i++) {
-    const long long len = ulen[i];
-    char head[160];
-    int hn = snprintf(head, sizeof(head), ">%llu LN:i:%lld KC:i:%lld km:f:%d", (unsigned long long)i, len, (long long)med[i] * (len - (long long)k + 1), med[i]);
-    line.assign(head, (size_t)hn);
-    for (int x = 0; x < 8; x++) {
-      const int32_t v = links[i * 8 + x];
-      if (!v) continue;
-      hn = snprintf(head, sizeof(head), " L:%c:%d:%c", x < 4 ? '+' : '-', (v > 0 ? v : -v) - 1, v > 0 ? '+' : '-');
-      line.append(head, (size_t)hn);
+  // the records as the reference writes them (:606-626): ids 0-based in final numbering, successors then predecessors.
+  // Formatted in slices by a few host threads (two million records are ~6 M numbers to print), written in order
+  {
+    const auto put_num = [](std::string &o, long long v) {
+      char t[24]; int n = 0;
+      unsigned long long a = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+      do { t[n++] = (char)('0' + a % 10); a /= 10; } while (a);
+      if (v < 0) o.push_back('-');
+      while (n) o.push_back(t[--n]);
+    };
+    const auto format = [&](uint64_t a, uint64_t b, std::string &o) {
+      o.clear();
+      for (uint64_t i = a; i < b; i++) {
+        const long long len = ulen[i];
+        o.push_back('>'); put_num(o, (long long)i);
+        o.append(" LN:i:"); put_num(o, len);
+        o.append(" KC:i:"); put_num(o, (long long)med[i] * (len - (long long)k + 1));
+        o.append(" km:f:"); put_num(o, med[i]);
+        for (int x = 0; x < 8; x++) {
+          const int32_t v = links[i * 8 + x];
+          if (!v) continue;
+          o.append(x < 4 ? " L:+:" : " L:-:"); put_num(o, (v > 0 ? v : -v) - 1);
+          o.append(v > 0 ? ":+" : ":-");
+        }
+        o.push_back('\n');
+        o.append(bases.data() + uoff[i], (size_t)len);
+        o.push_back('\n');
+      }
+    };
+    const uint64_t slice = 1u << 15;
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : nt > 8 ? 8 : nt;
+    std::vector<std::string> outs(nt);
+    for (uint64_t a0 = 0; a0 < nunits; a0 += slice * nt) {
+      std::vector<std::thread> th;
+      unsigned used = 0;
+      for (unsigned t = 0; t < nt && a0 + t * slice < nunits; t++, used++) {
+        const uint64_t a = a0 + t * slice, b = a + slice < nunits ? a + slice : nunits;
+        if (nt == 1) format(a, b, outs[0]);
+        else th.emplace_back(format, a, b, std::ref(outs[t]));
+      }
+      for (auto &x : th) x.join();
+      for (unsigned t = 0; t < used; t++)
+        if (fwrite(outs[t].data(), 1, outs[t].size(), fo) != outs[t].size()) rc = SHK_ERR_IO;
     }
-    line.push_back('\n');
-    line.append(bases.data() + uoff[i], (size_t)len);
-    line.push_back('\n');
-    fwrite(line.data(), 1, line.size(), fo);
   }
-  fclose(fo);
+  if (fclose(fo) != 0) rc = SHK_ERR_IO;
+  if (rc) return finish(c, rc);
   const unsigned long long *ds = reinterpret_cast<const unsigned long long *>(u->h_scal + 4);
   u->st.unitigs = nunits; u->st.total_len = total;
   if (nunits) { u->st.extensions = ds[0]; u->st.duplicates = ds[1]; u->st.truncated = ds[2]; }
