@@ -551,7 +551,16 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
         hipLaunchKernelGGL(k_rp_slot_cursors, dim3((uint32_t)((nb * P) / 256 + 1 < 4096 ? (nb * P) / 256 + 1 : 4096)), dim3(256), 0, c->stream, cursor, nb * P, cap);
       } else {
         const bool ready = (l == 0 && hist0_ready) || (l == 1 && hist1_ready);
-        if (!ready) {
+        if (!ready && l == 0 && c->nlevels >= 2 && c->lv[0].bits + c->lv[1].bits <= 14 && c->lv[1].ng_log2 == 0 && !getenv("SHK_RP_HIST1")) {
+          // the first pass over unsorted words counts the second level's digits as well (k_rp_hist2)
+          HIPCHK(hipMemsetAsync(c->d_hist[0], 0, (P << c->lv[0].ng_log2) * 8, c->stream));
+          HIPCHK(hipMemsetAsync(c->d_hist[1], 0, (P << c->lv[1].bits) * 8, c->stream));
+          ProfScope ps(c, KP_RP_HIST);
+          const uint32_t wt = nwin / 1024 + 1;   // windows per workgroup (few workgroups: each flushes up to 2^14 counters)
+          hipLaunchKernelGGL((k_rp_hist2<14>), dim3(nwin / wt + 1), dim3(c->threads < 512 ? c->threads : 512), 0, c->stream, in, n_p, c->lv[0], c->lv[1],
+                             c->d_hist[0], c->d_hist[1], wt);
+          hist1_ready = true;
+        } else if (!ready) {
           HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream));
           ProfScope ps(c, KP_RP_HIST);
           const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
