@@ -312,7 +312,8 @@ def main():
         def exchange(self, s):
             t = texts[s]
             # (a rank-local failure of the hash or the routing is raised on every rank after the exchange's all-gather)
-            return shkdist.hash_and_exchange(self.ctx, t.data_ptr(), offs, lens, hb, world, rank, device, on_device=True, text_bytes=t.numel())
+            return shkdist.hash_and_exchange(self.ctx, t.data_ptr(), offs, lens, hb, world, rank, device, on_device=True, text_bytes=t.numel(),
+                                             keep_own=True)
 
         def step(self, s, nsteps):
             ctx, t = self.ctx, texts[s]
@@ -357,7 +358,7 @@ def main():
                 lap()
                 recv = ex.wait()
                 lap()
-                shkdist.stage_received(ctx, self.sstate, recv)     # (a local failure surfaces on every rank in sharded_count)
+                shkdist.stage_received(ctx, self.sstate, recv, own=ex.own)     # (a local failure surfaces on every rank in sharded_count)
                 lap()
                 st = shkdist.sharded_count(ctx, self.sstate, len(offs) * world)   # counts are whole-job (all-reduced)
                 lap()

@@ -184,6 +184,10 @@ int shk_hash_route_chunks(shk_ctx *ctx, const void *text, int text_on_device, ui
                           const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks, uint32_t nshards,
                           uint64_t **d_out, uint64_t *counts, uint64_t *nwords);
 int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
+/* The same from TWO device buffers (a shard's own words, where shk_hash_route_chunks left them, and the words it received):
+ * no copy that brings them together first. Neither may lie in the buffer shk_hash_chunks returns (the first partition
+ * level writes there): SHK_ERR_ARG. */
+int shk_stage_words_pair(shk_ctx *ctx, const uint64_t *d_words_a, uint64_t nwords_a, const uint64_t *d_words_b, uint64_t nwords_b);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                       int want_hist, shk_summary *out);
 int shk_stage_commit(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, const shk_summary *s);

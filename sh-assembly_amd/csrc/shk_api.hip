@@ -93,6 +93,8 @@ struct shk_ctx {
   uint32_t region_cap;          // how the partitioned words lie: 0 = d_base[nlevels] holds exact offsets; else region r owns the slot
                                 // [r * region_cap, ...) and d_base[nlevels][r] is its END (ShkRpLevel::slot_cap)
   uint32_t slot_overflows;      // consecutive batches whose slotted last level overflowed; at 2 the slots are switched off
+  const uint64_t *stage2_b;     // shk_stage_words_pair: the second source of the first partition level (null = one source)
+  uint64_t stage2_na, stage2_nb;
   int slots_off;
   uint32_t pt_lo, pt_split, pt_hi; int pt_valid; uint64_t pt_nprot;   // one-pass deNoise point in progress (shk_stage_point_*)
   const uint64_t *pt_words;     // its words (null: a round on its own, shk_stage_round_try)
@@ -268,6 +270,7 @@ extern "C" int shk_create(const shk_config *cfg, shk_ctx **out) {
   c->use_spill = (getenv("SHK_TWO_LAUNCH") || c->single_ok) ? 0 : 1;
   // the sampled location of a deNoise point needs enough regions for the sample to mean something
   c->region_cap = 0; c->slot_overflows = 0; c->slots_off = getenv("SHK_NO_SLOTS") ? 1 : 0;
+  c->stage2_b = nullptr; c->stage2_na = c->stage2_nb = 0;
   // every 8th region; every 16th from 2^20 regions on (qb >= 28): a wrong guess costs one more one-pass point (18 ms at
   // qb 29), the sample 1.9 / 1.15 / 0.75 ms at stride 8 / 16 / 32; measured on the 12 points of the qb-29 bench: no wrong
   // guess at 8 and 16, one at 32 (its chance grows with sqrt(stride) / sqrt(new keys per batch))
@@ -522,8 +525,21 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
   const uint64_t *in = ext ? ext : c->d_words[src];
   int cur = ext ? 1 : src;   // the buffer `in` occupies (an external source leaves both free: write to d_words[0] first)
   c->region_cap = 0;
+  // shk_stage_words_pair: the first level reads TWO buffers (the words a shard kept for itself, where the routing left them,
+  // and the words it received): both are counted into one histogram and scattered with one set of cursors. Their
+  // lengths and one-bucket base arrays live in d_scalars[40..45].
+  const uint64_t *in2 = (ext && first_level == 0) ? c->stage2_b : nullptr;
+  const uint64_t n_a = in2 ? c->stage2_na : nmax, n_b = in2 ? c->stage2_nb : 0;
   for (uint32_t l = first_level; l < c->nlevels; l++) {
     const uint64_t nb = c->lv[l].nbuckets, P = 1ULL << c->lv[l].bits;
+    // the sources of this level: (words, their number on the device, their bucket bases, their number on the host)
+    struct Src { const uint64_t *w, *n_p, *base; uint64_t n; } srcs[2] = {{in, n_p, c->d_base[l], nmax}, {nullptr, nullptr, nullptr, 0}};
+    int nsrc = 1;
+    if (l == 0 && in2) {
+      srcs[0] = {in, c->d_scalars + 40, c->d_scalars + 42, n_a};
+      srcs[1] = {in2, c->d_scalars + 41, c->d_scalars + 44, n_b};
+      nsrc = 2;
+    }
     // Last level: fixed-capacity region slots instead of a histogram pass over the keys + scan, when the output buffer
     // (max_batch_keys 8-byte words = twice as many 4-byte records) gives every region room for its mean share of this
     // batch plus six sigma of a clumpy hash distribution (a true k-mer comes ~8 times per batch). A region that gets
@@ -557,14 +573,17 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
           HIPCHK(hipMemsetAsync(c->d_hist[1], 0, (P << c->lv[1].bits) * 8, c->stream));
           ProfScope ps(c, KP_RP_HIST);
           const uint32_t wt = nwin / 1024 + 1;   // windows per workgroup (few workgroups: each flushes up to 2^14 counters)
-          hipLaunchKernelGGL((k_rp_hist2<14>), dim3(nwin / wt + 1), dim3(c->threads < 512 ? c->threads : 512), 0, c->stream, in, n_p, c->lv[0], c->lv[1],
-                             c->d_hist[0], c->d_hist[1], wt);
+          for (int si = 0; si < nsrc; si++)
+            hipLaunchKernelGGL((k_rp_hist2<14>), dim3(nwin / wt + 1), dim3(c->threads < 512 ? c->threads : 512), 0, c->stream, srcs[si].w, srcs[si].n_p,
+                               c->lv[0], c->lv[1], c->d_hist[0], c->d_hist[1], wt);
           hist1_ready = true;
         } else if (!ready) {
           HIPCHK(hipMemsetAsync(c->d_hist[l], 0, ((nb * P) << c->lv[l].ng_log2) * 8, c->stream));
           ProfScope ps(c, KP_RP_HIST);
           const uint32_t wt = nwin / 4096 + 1;   // windows per workgroup
-          hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, in, n_p, c->d_base[l], c->d_tfb, c->lv[l], c->d_hist[l], wt);
+          for (int si = 0; si < nsrc; si++)
+            hipLaunchKernelGGL(k_rp_hist, dim3(nwin / wt + 1), dim3(c->threads), 0, c->stream, srcs[si].w, srcs[si].n_p, srcs[si].base, c->d_tfb, c->lv[l],
+                               c->d_hist[l], wt);
         }
         if (c->lv[l].ng_log2) {
           // (first level only: nb = 1) sub-buckets in (digit, group) order; the next level's buckets are the digits
@@ -579,17 +598,20 @@ static int partition_stage(shk_ctx *c, int src, uint64_t nmax, int *dst, const u
         }
       }
       { ProfScope ps(c, KP_RP_SCATTER);
-        if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
-          hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
-                             c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, cursor, c->d_err);
-        else if (c->threads >= 512 && l + 1 < c->nlevels && c->lv[l].bits <= 8 && !getenv("SHK_RP_NARROW"))
-          // a level in the middle: 16384-key windows as at the first level (digit runs of 1 KB instead of 256 bytes:
-          // 2.85 -> 2.25 ms per 832 M keys). Not the last level: its 4-byte records in slots gain nothing (3.4 ms either way)
-          hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024, 256>), dim3((uint32_t)(nmax >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, in,
-                             c->d_words[cur ^ 1], n_p, c->d_base[l], c->d_tfb, lvl, cursor, c->d_err);
-        else
-          hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3(nwin), dim3(SHK_RP_THREADS), 0, c->stream, in, c->d_words[cur ^ 1], n_p,
-                             c->d_base[l], c->d_tfb, lvl, cursor, c->d_err); }
+        for (int si = 0; si < nsrc; si++) {
+          const Src &S = srcs[si];
+          if (l == 0 && c->lv[0].ng_log2)      // (window groups are defined on the first level's 16384-key windows: SHK_RP_TILE0_LOG2)
+            hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024>), dim3((uint32_t)(S.n >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, S.w,
+                               c->d_words[cur ^ 1], S.n_p, S.base, c->d_tfb, lvl, cursor, c->d_err);
+          else if (c->threads >= 512 && l + 1 < c->nlevels && c->lv[l].bits <= 8 && !getenv("SHK_RP_NARROW"))
+            // a level in the middle: 16384-key windows as at the first level (digit runs of 1 KB instead of 256 bytes:
+            // 2.85 -> 2.25 ms per 832 M keys). Not the last level: its 4-byte records in slots gain nothing (3.4 ms either way)
+            hipLaunchKernelGGL((k_rp_scatter<SHK_RP_TILE0_LOG2, 1024, 256>), dim3((uint32_t)(S.n >> SHK_RP_TILE0_LOG2) + 1), dim3(1024), 0, c->stream, S.w,
+                               c->d_words[cur ^ 1], S.n_p, S.base, c->d_tfb, lvl, cursor, c->d_err);
+          else
+            hipLaunchKernelGGL((k_rp_scatter<12, SHK_RP_THREADS>), dim3((uint32_t)(S.n / SHK_RP_TILE + 1)), dim3(SHK_RP_THREADS), 0, c->stream, S.w,
+                               c->d_words[cur ^ 1], S.n_p, S.base, c->d_tfb, lvl, cursor, c->d_err);
+        } }
       if (!cap) break;
       uint32_t bits = 0;
       if (fetch_err(c, &bits)) return SHK_ERR_HIP;
@@ -1743,6 +1765,28 @@ extern "C" int shk_hash_route_chunks(shk_ctx *c, const void *text, int text_on_d
   HIPCHK(hipGetLastError());
   *d_out = send;
   return finish(c, 0);
+}
+
+extern "C" int shk_stage_words_pair(shk_ctx *c, const uint64_t *d_a, uint64_t na, const uint64_t *d_b, uint64_t nb) {
+  if (!c || (!d_a && na) || (!d_b && nb)) return SHK_ERR_ARG;
+  if (na == 0) return shk_stage_words(c, d_b, nb);
+  if (nb == 0) return shk_stage_words(c, d_a, na);
+  if (na + nb > c->cfg.max_batch_keys) return SHK_ERR_BATCH;
+  // (the first level writes d_words[0] while it reads both sources)
+  { const uint64_t *o0 = c->d_words[0], *o1 = c->d_words[0] + c->cfg.max_batch_keys + 1;
+    if ((d_a + na > o0 && d_a < o1) || (d_b + nb > o0 && d_b < o1)) return SHK_ERR_ARG; }
+  if (c->nlevels == 0) return SHK_ERR_ARG;       // (a single region has no partition to read two sources: concatenate)
+  HIPCHK(hipSetDevice(c->dev));
+  c->h_pinned[43] = na + nb;
+  c->h_pinned[56] = na; c->h_pinned[57] = nb; c->h_pinned[58] = 0; c->h_pinned[59] = na; c->h_pinned[60] = 0; c->h_pinned[61] = nb;
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 1, c->h_pinned + 43, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_scalars + 40, c->h_pinned + 56, 48, hipMemcpyHostToDevice, c->stream));
+  c->stage2_b = d_b; c->stage2_na = na; c->stage2_nb = nb;
+  int dst = 0;
+  int rc = partition_stage(c, 0, na + nb, &dst, d_a);
+  c->stage2_b = nullptr;
+  c->staged = dst;
+  return finish(c, rc);
 }
 
 extern "C" int shk_stage_words(shk_ctx *c, const uint64_t *d_words, uint64_t nwords) {

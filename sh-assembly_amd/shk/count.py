@@ -134,10 +134,10 @@ def main(argv=None):
     def start(first_global):
         text, offs, lens, seen, err = next_batch(first_global)
         if err:                                    # SHK_ERR_IO: "Error: Wrong input file!"
-            return shkdist.Exchange(ctx, 0, qb + 8, world, rank, device, local_rc=-6), seen
+            return shkdist.Exchange(ctx, 0, qb + 8, world, rank, device, local_rc=-6, keep_own=True), seen
         # hash + bin by owner + start the exchange (a rank without a part in the last, ragged batch takes part with no
         # words; a local failure is raised on every rank)
-        return shkdist.hash_and_exchange(ctx, text, offs, lens, qb + 8, world, rank, device), seen
+        return shkdist.hash_and_exchange(ctx, text, offs, lens, qb + 8, world, rank, device, keep_own=True), seen
 
     hb = qb + 8
     first = 0
@@ -149,7 +149,7 @@ def main(argv=None):
             nxt = start(first + seen)              # the next batch's exchange runs while this one is counted
         if seen:
             recv = ex.wait()
-            shkdist.stage_received(ctx, st, recv)
+            shkdist.stage_received(ctx, st, recv, own=ex.own)
             o = shkdist.sharded_count(ctx, st, seen)
             for kk in totals:
                 totals[kk] += o[kk]

@@ -506,7 +506,7 @@ class Exchange:
     two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
     behind compute: xGMI moves 8 B per routed key while the CUs hash."""
 
-    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True, local_rc=0, routed=None):
+    def __init__(self, ctx, nwords, hb, world, rank, device, async_op=True, local_rc=0, routed=None, keep_own=False):
         # local_rc: the return code of the rank-local work in front of this exchange (shk_hash_chunks), 0 = fine.
         # A rank-local failure -- there, or in shk_route_words here -- must not keep this rank out of the all-gather its
         # peers enter: the code travels in the gathered vector (one extra column) and EVERY rank raises after the gather.
@@ -532,17 +532,31 @@ class Exchange:
         allc = [row[:world] for row in allc]
         self.send = wrap_words(dp, nwords, device)
         rc = [allc[p][rank] for p in range(world)]
-        mx = max(max(row) for row in allc)
         # every rank sees every bin size: a shard that would receive more than it can stage fails on ALL ranks here
         # (contexts of one job are created alike), not on its own rank inside a collective the others then wait in
         cap = int(ctx.cfg.max_batch_keys)
         worst = max(sum(allc[p][r] for p in range(world)) for r in range(world))
         if worst > cap:
             raise ShkError(-7, "a shard would receive %d key words, more than max_batch_keys (%d)" % (worst, cap))
-        self.recv = _recv_buffer(ctx, sum(rc), device)
+        # keep_own (a decision of the whole job: every rank passes the same flag): the words a rank owns itself stay where
+        # the routing left them -- `own` = (device pointer, count) inside its send buffer, valid until the call after
+        # next of shk_hash_route_chunks / shk_route_words -- and shk_stage_words_pair reads them from there next to the
+        # received ones: 1/world of the words never goes through the collective (with one rank: none does)
+        self.own = (0, 0)
         soff = [sum(sc[:p]) for p in range(world)]
+        if keep_own:
+            if dp and sc[rank]:
+                self.own = (int(dp) + 8 * soff[rank], int(sc[rank]))
+            for p in range(world):
+                allc[p][p] = 0
+            rc[rank] = 0
+            sc = [0 if p == rank else sc[p] for p in range(world)]      # (soff stays: the bins' places in the send buffer)
+        mx = max(max(row) for row in allc)
+        self.recv = _recv_buffer(ctx, sum(rc), device)
         roff = [sum(rc[:p]) for p in range(world)]
         self.work = []
+        if keep_own and world == 1:
+            return
         if world == 1 and device.type != "cuda":
             self.recv.copy_(self.send)
             return
@@ -576,8 +590,9 @@ class Exchange:
         return self.recv
 
 
-def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=False, text_bytes=None, async_op=True):
-    """shk_hash_chunks + Exchange with the rank-local failure of either carried to every rank (see Exchange)"""
+def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=False, text_bytes=None, async_op=True, keep_own=False):
+    """shk_hash_chunks + Exchange with the rank-local failure of either carried to every rank (see Exchange).
+    keep_own: the rank's own words are not copied (Exchange.own; stage with stage_received(..., own=ex.own))"""
     rc, nw, routed = 0, 0, None
     try:
         if offs and not os.environ.get("SHK_NO_ROLL"):
@@ -588,13 +603,17 @@ def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=
             _, nw = ctx.hash_chunks(text, offs, lens, on_device=on_device, text_bytes=text_bytes)
     except ShkError as e:
         rc = e.code
-    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc, routed=routed)
+    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc, routed=routed, keep_own=keep_own)
 
 
-def stage_received(ctx, st, recv):
+def stage_received(ctx, st, recv, own=None):
     """shk_stage_words in front of a collective decision: a rank-local failure is parked in the shard state and shown
-    to the peers by the next all-reduce (sharded_count raises it on every rank)"""
-    _local(st, lambda: ctx.stage_words(recv.data_ptr(), recv.numel()))
+    to the peers by the next all-reduce (sharded_count raises it on every rank). own = Exchange.own: the rank's own
+    words are read where the routing left them (shk_stage_words_pair)"""
+    if own and own[1]:
+        _local(st, lambda: ctx.stage_words_pair(own[0], own[1], recv.data_ptr() if recv.numel() else 0, recv.numel()))
+    else:
+        _local(st, lambda: ctx.stage_words(recv.data_ptr(), recv.numel()))
 
 
 def route_words(ctx, nwords, hb, world, rank, device):

@@ -50,7 +50,12 @@ def _worker(rank, world, port, q, nd=ND, out_path=None, ml=ML, trig=TRIG, shape=
     for e, n in ((ex, half), (ex2, len(offs) - half)):
         recv = e.wait()
         allw.append(recv.clone())
-        ctx.stage_words(recv.data_ptr(), recv.numel())
+        if rank % 2 and recv.numel() > 40:      # (odd ranks: from two buffers, shk_stage_words_pair)
+            m = recv.numel() // 3 + 17
+            pa, pb = recv[:m].clone(), recv[m:].clone()
+            ctx.stage_words_pair(pa.data_ptr(), pa.numel(), pb.data_ptr(), pb.numel())
+        else:
+            ctx.stage_words(recv.data_ptr(), recv.numel())
         o = shkdist.sharded_count(ctx, st, n * world)
         for kk in out:
             out[kk] += o[kk]

@@ -242,10 +242,12 @@ def test_large_scale_properties(tmp_path):
     assert digests[0] == digests[1]
 
 
-def test_sharded_flow_one_rank_matches_oracle(monkeypatch):
+@pytest.mark.parametrize("two_sources", [False, True])
+def test_sharded_flow_one_rank_matches_oracle(monkeypatch, two_sources):
     """The multi-GPU flow (hash -> route -> all-to-all -> stage -> collective try/accept, shk/dist.py) with
     one rank over RCCL: one shard is the whole filter, so the table must equal the oracle's byte for byte,
-    deNoise rounds included."""
+    deNoise rounds included. two_sources: the words are staged from two buffers (shk_stage_words_pair: a rank's own words
+    and the received ones are never copied together), cut at an arbitrary place."""
     import torch
     import torch.distributed as dist
     from shk import dist as shkdist
@@ -268,7 +270,12 @@ def test_sharded_flow_one_rank_matches_oracle(monkeypatch):
         for a, b in ((0, third), (third, 2 * third), (2 * third, len(offs))):   # three batches
             _, nw = ctx.hash_chunks(fq, offs[a:b], lens[a:b])
             recv = shkdist.route_words(ctx, nw, qb + 8, 1, 0, dev)
-            ctx.stage_words(recv.data_ptr(), recv.numel())
+            if two_sources:
+                m = recv.numel() // 3 + 17
+                pa, pb = recv[:m].clone(), recv[m:].clone()
+                ctx.stage_words_pair(pa.data_ptr(), pa.numel(), pb.data_ptr(), pb.numel())
+            else:
+                ctx.stage_words(recv.data_ptr(), recv.numel())
             out = shkdist.sharded_count(ctx, st, b - a)
             rounds += out["denoise_rounds"]
             removed += out["removed"]

@@ -86,6 +86,16 @@ def main():
             for i in range(0, len(offs), step):
                 if args.sharded:
                     if rnd.random() < 0.5:      # hash + bin by owner in one pass (roll kernels) ...
+                        if rnd.random() < 0.5:  # ... its own words staying in the send buffer (shk_stage_words_pair reads them there) ...
+                            ex = shkdist.hash_and_exchange(ctx, fq, offs[i:i + step], lens[i:i + step], qb + 8, 1, 0, dev, async_op=False, keep_own=True)
+                            recv = ex.wait()
+                            if ex.own[1]:
+                                ctx.stage_words_pair(ex.own[0], ex.own[1], 0, 0)
+                            else:
+                                ctx.stage_words(0, 0)
+                            st = shkdist.sharded_count(ctx, sst, len(offs[i:i + step]))
+                            rounds += st["denoise_rounds"]; removed += st["removed"]
+                            continue
                         recv = shkdist.hash_and_exchange(ctx, fq, offs[i:i + step], lens[i:i + step], qb + 8, 1, 0, dev, async_op=False).wait()
                     else:                       # ... or the wave-scan hash kernel and the routing pass
                         _, nw = ctx.hash_chunks(fq, offs[i:i + step], lens[i:i + step])
