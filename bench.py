@@ -303,6 +303,8 @@ def main():
             self.ctx = new_ctx()
             if not sharded and not args.serial and not args.host_text:
                 self.ctx.prepare_reserve()       # (the overlapped front end's buffers: context set-up, like the table's own)
+            if sharded:                          # (the exchange's buffers too: two send buffers in the library, two receive tensors)
+                shkdist.reserve_exchange(self.ctx, device)
             self.sstate = shkdist.ShardState(trigger, nd, device) if sharded else None
             self.counted = self.removed = self.rounds = 0
             self.uploaded = {}
@@ -348,8 +350,14 @@ def main():
 
                 def lap():          # diagnostics (--trace): where a sharded step spends its time
                     if args.trace:
-                        torch.cuda.synchronize()
+                        if not os.environ.get("SHK_TRACE_NOSYNC"):
+                            torch.cuda.synchronize()
                         tm.append(time.perf_counter())
+                    elif os.environ.get("SHK_DIST_TIMING"):
+                        tm.append(time.perf_counter())
+                        if len(tm) == 5:
+                            ph = getattr(self, "phase_s", [0.0] * 4)
+                            self.phase_s = [ph[i] + tm[i + 1] - tm[i] for i in range(4)]
                 if s not in self.inflight:
                     self.inflight[s] = self.exchange(s)
                 ex = self.inflight.pop(s)
@@ -399,13 +407,24 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if os.environ.get("SHK_DIST_STACKS"):      # diagnostics: where the threads are, every 100 ms of the timed region
+        import faulthandler
+        import threading
+        print("threads:", [t.name for t in threading.enumerate()], file=sys.stderr, flush=True)
+        faulthandler.dump_traceback_later(0.1, repeat=True, file=sys.stderr)
     t0 = time.perf_counter()
     for s in range(args.steps):
         run.step(s, args.steps)
     torch.cuda.synchronize()
+    if os.environ.get("SHK_DIST_STACKS"):
+        faulthandler.cancel_dump_traceback_later()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if sharded and rank == 0 and os.environ.get("SHK_DIST_TIMING"):
+        print("small collectives: %d, %.1f ms in all (build %.1f ms); phases hash+route+exchange / wait / stage / count: %s ms" % (
+            shkdist.COLLECTIVE_SECONDS[1], 1e3 * shkdist.COLLECTIVE_SECONDS[0], 1e3 * dt, ["%.0f" % (1e3 * x) for x in getattr(run, "phase_s", [])] + ["lib %.0f" % (1e3 * shkdist.HASH_EXCHANGE_SECONDS[0]), "exch %.0f" % (1e3 * shkdist.HASH_EXCHANGE_SECONDS[1])]),
+              file=sys.stderr, flush=True)
     prof = ctx.profile_get()
     end = ctx.totals()
     if dist:

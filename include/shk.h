@@ -187,6 +187,9 @@ int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 /* The same from TWO device buffers (a shard's own words, where shk_hash_route_chunks left them, and the words it received):
  * no copy that brings them together first. Neither may lie in the buffer shk_hash_chunks returns (the first partition
  * level writes there): SHK_ERR_ARG. */
+/* Allocates the two send buffers of shk_route_words / shk_hash_route_chunks now instead of inside their first two calls
+ * (for callers that keep set-up and steady state apart). Idempotent. */
+int shk_route_reserve(shk_ctx *ctx);
 int shk_stage_words_pair(shk_ctx *ctx, const uint64_t *d_words_a, uint64_t nwords_a, const uint64_t *d_words_b, uint64_t nwords_b);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,
                       int want_hist, shk_summary *out);

@@ -1767,6 +1767,14 @@ extern "C" int shk_hash_route_chunks(shk_ctx *c, const void *text, int text_on_d
   return finish(c, 0);
 }
 
+extern "C" int shk_route_reserve(shk_ctx *c) {
+  if (!c) return SHK_ERR_ARG;
+  HIPCHK(hipSetDevice(c->dev));
+  for (int b = 0; b < 2; b++)
+    if (!c->d_send[b] && dmalloc(&c->d_send[b], c->cfg.max_batch_keys + 1)) return SHK_ERR_HIP;
+  return SHK_OK;
+}
+
 extern "C" int shk_stage_words_pair(shk_ctx *c, const uint64_t *d_a, uint64_t na, const uint64_t *d_b, uint64_t nb) {
   if (!c || (!d_a && na) || (!d_b && nb)) return SHK_ERR_ARG;
   if (na == 0) return shk_stage_words(c, d_b, nb);

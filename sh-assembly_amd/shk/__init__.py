@@ -65,7 +65,7 @@ class ShkError(RuntimeError):
 
 
 EXPORTS = ["shk_create", "shk_destroy", "shk_count_chunks", "shk_hash_chunks", "shk_count_words", "shk_route_words", "shk_stage_words",
-           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_stage_sample", "shk_stage_point_try", "shk_stage_round_try", "shk_stage_point_walk", "shk_stage_point_finish", "shk_upload_text", "shk_prepare_chunks", "shk_count_prepared", "shk_prepare_reserve", "shk_stage_words_pair", "shk_hash_route_chunks", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
+           "shk_stage_summary", "shk_stage_commit", "shk_stage_try", "shk_stage_try_denoise", "shk_stage_accept", "shk_stage_chunk_hist", "shk_stage_sample", "shk_stage_point_try", "shk_stage_round_try", "shk_stage_point_walk", "shk_stage_point_finish", "shk_upload_text", "shk_prepare_chunks", "shk_count_prepared", "shk_prepare_reserve", "shk_stage_words_pair", "shk_route_reserve", "shk_hash_route_chunks", "shk_host_alloc", "shk_host_free", "shk_extend_forward", "shk_unitigs_from_seeds", "shk_find_unitigs", "shk_unitig_set_new", "shk_unitig_set_free",
            "shk_unitigs_add_seeds", "shk_unitig_set_write", "shk_select_seeds", "shk_denoise",
            "shk_stats", "shk_header", "shk_export_blocks", "shk_export_cqf", "shk_import_cqf", "shk_import_blocks",
            "shk_lookup", "shk_profile_enable", "shk_profile_get", "shk_profile_reset", "shk_strerror",
@@ -315,6 +315,11 @@ class Context:
         cnt = (C.c_uint64 * nshards)()
         self._chk(self.L.shk_route_words(self.h, nwords, nshards, C.byref(dp), cnt))
         return dp.value, [cnt[i] for i in range(nshards)]
+
+    def route_reserve(self):
+        """allocate the send buffers of the routing now rather than in its first calls"""
+        self.L.shk_route_reserve.argtypes = [C.c_void_p]
+        self._chk(self.L.shk_route_reserve(self.h))
 
     def stage_words_pair(self, d_a, na, d_b, nb):
         """partition the words of TWO device buffers for the collective flow (shk_stage_words_pair)"""

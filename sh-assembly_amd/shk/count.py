@@ -108,6 +108,7 @@ def main(argv=None):
                       max_batch_keys=max(1 << 16, int(1.5 * cap_bytes)), max_batch_reads=cap_bytes // 16 + 1024,
                       device=local_rank if a.backend == "nccl" else 0, shard_index=rank, num_shards=world, lib_path=a.lib,
                       **({"threads_per_group": 64, "hash_groups": 2} if a.backend == "gloo" else {}))
+    shkdist.reserve_exchange(ctx, device)
     st = shkdist.ShardState(trigger, rounds, device)
     arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
     bh = H.shkh_batch_open(arr, len(files), mode, a.part_size, a.overhead)

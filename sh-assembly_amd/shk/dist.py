@@ -40,11 +40,20 @@ class ShardState:
         self.keep = None
 
 
+HASH_EXCHANGE_SECONDS = [0.0, 0.0]  # diagnostics: wall time in the library's hash + route call / in starting the exchange
+COLLECTIVE_SECONDS = [0.0, 0]      # diagnostics: wall time spent in the small collectives (with their host round trip), and their number
+
+
 def _allreduce(vals, st, op=None):
+    import time
+    t0 = time.perf_counter()
     t = torch.tensor(vals, dtype=torch.int64, device=st.device)
     dist.all_reduce(t, op=op or dist.ReduceOp.SUM)
     st.collectives += 1
-    return [int(x) for x in t.tolist()]
+    out = [int(x) for x in t.tolist()]
+    COLLECTIVE_SECONDS[0] += time.perf_counter() - t0
+    COLLECTIVE_SECONDS[1] += 1
+    return out
 
 
 def _local(st, call, default=None):
@@ -501,6 +510,16 @@ def _recv_buffer(ctx, n, device):
     return pool["bufs"][i][:n]
 
 
+def reserve_exchange(ctx, device):
+    """allocate the exchange's buffers (the library's two send buffers, the two receive tensors) at set-up time. Left to
+    their first use they are allocated inside the first steps of a build -- 10 GB each at the bench's batch size -- and on
+    an MI355X that made about every second run of `bench.py --force-dist` three to four times slower per step, for the
+    whole build, with unchanged kernel times (measured; with the reservation: 8 of 8 runs at 38 ms per step)"""
+    ctx.route_reserve()
+    for _ in range(2):
+        _recv_buffer(ctx, 0, device)
+
+
 class Exchange:
     """one all-to-all of key words in flight: start() after shk_route_words, wait() before shk_stage_words. Between the
     two the caller may hash and route the NEXT batch (the library keeps two send buffers), which hides the exchange
@@ -593,6 +612,8 @@ class Exchange:
 def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=False, text_bytes=None, async_op=True, keep_own=False):
     """shk_hash_chunks + Exchange with the rank-local failure of either carried to every rank (see Exchange).
     keep_own: the rank's own words are not copied (Exchange.own; stage with stage_received(..., own=ex.own))"""
+    import time
+    t0 = time.perf_counter()
     rc, nw, routed = 0, 0, None
     try:
         if offs and not os.environ.get("SHK_NO_ROLL"):
@@ -603,7 +624,11 @@ def hash_and_exchange(ctx, text, offs, lens, hb, world, rank, device, on_device=
             _, nw = ctx.hash_chunks(text, offs, lens, on_device=on_device, text_bytes=text_bytes)
     except ShkError as e:
         rc = e.code
-    return Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc, routed=routed, keep_own=keep_own)
+    t1 = time.perf_counter()
+    ex = Exchange(ctx, nw, hb, world, rank, device, async_op=async_op, local_rc=rc, routed=routed, keep_own=keep_own)
+    HASH_EXCHANGE_SECONDS[0] += t1 - t0
+    HASH_EXCHANGE_SECONDS[1] += time.perf_counter() - t1
+    return ex
 
 
 def stage_received(ctx, st, recv, own=None):
