@@ -1064,14 +1064,48 @@ __device__ __forceinline__ ShkMP shk_region_mp(const uint32_t *summary, uint32_t
   }
   return m;
 }
+// A tile's (T, c) pairs, read ONCE and coalesced into LDS (lane i takes record i: a thread that walked its own `per`
+// consecutive 32-byte records touched 64 lines per load, and the records came up from memory a dozen times: 0.78 GB per
+// launch for 67 MB of summaries, profiles/r03_e_pmc_traffic.txt); stats[0..3] += the four statistics words of the records
+// this thread loaded (stride >= 6 only)
+__device__ __forceinline__ void shk_scan_tile_load(const uint32_t *summary, uint32_t base, uint32_t nregions, uint32_t stride, uint2 *ac,
+                                                   uint64_t *stats) {
+  for (uint32_t i = threadIdx.x; i < SHK_RSCAN_TILE; i += blockDim.x) {
+    const uint32_t r = base + i;
+    uint2 v = make_uint2(0u, 0u);
+    if (r < nregions) {
+      if (stride == SHK_SUM_STRIDE) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(summary + (size_t)SHK_SUM_STRIDE * r);
+        v = make_uint2(lo.x, lo.y);
+        if (stats) {
+          const uint2 hi = *reinterpret_cast<const uint2 *>(summary + (size_t)SHK_SUM_STRIDE * r + 4);
+          stats[0] += lo.z; stats[1] += lo.w; stats[2] += hi.x; stats[3] += hi.y;
+        }
+      } else {
+        v = make_uint2(summary[(size_t)stride * r], summary[(size_t)stride * r + 1]);
+        if (stats && stride >= 6)
+          for (int z = 0; z < 4; z++) stats[z] += summary[(size_t)stride * r + 2 + z];
+      }
+    }
+    ac[i] = v;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ ShkMP shk_tile_mp(const uint2 *ac, uint32_t i, uint32_t r) {
+  ShkMP m; m.a = ac[i].x; m.b = SHK_NEG_INF;
+  if (ac[i].y) m.b = (long long)r * SHK_REGION + ac[i].y;
+  return m;
+}
 // a: one workgroup per tile -> the tile's composed function
 // (stride = words per region record: SHK_SUM_STRIDE for the summaries, 2 for the intermediate table of a one-pass deNoise point)
 __global__ void k_region_scan_a(const uint32_t *summary, uint32_t nregions, long long *tile_a, long long *tile_b, uint32_t stride = SHK_SUM_STRIDE) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
+  __shared__ uint2 ac[SHK_RSCAN_TILE];
   const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
   const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
+  shk_scan_tile_load(summary, base, nregions, stride, ac, nullptr);
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
-  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, base + threadIdx.x * per + j, nregions, stride));
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_tile_mp(ac, threadIdx.x * per + j, base + threadIdx.x * per + j));
   ShkMP tot;
   shk_block_exscan_mp(mine, &tot, mpa, mpb);
   if (threadIdx.x == 0) { tile_a[blockIdx.x] = tot.a; tile_b[blockIdx.x] = tot.b; }
@@ -1103,11 +1137,14 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
                                 uint32_t stride = SHK_SUM_STRIDE) {
   __shared__ long long mpa[SHK_MAX_WAVES + 1], mpb[SHK_MAX_WAVES + 1];
   __shared__ uint64_t scratch64[SHK_MAX_WAVES + 1];
+  __shared__ uint2 ac[SHK_RSCAN_TILE];
   const uint32_t base = blockIdx.x * SHK_RSCAN_TILE;
   const uint32_t per = SHK_RSCAN_TILE / blockDim.x;
   const uint32_t r0 = base + threadIdx.x * per;
+  uint64_t stats[4] = {0, 0, 0, 0};
+  shk_scan_tile_load(summary, base, nregions, stride, ac, stats);
   ShkMP mine; mine.a = 0; mine.b = SHK_NEG_INF;
-  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_region_mp(summary, r0 + j, nregions, stride));
+  for (uint32_t j = 0; j < per; j++) mine = shk_mp_compose(mine, shk_tile_mp(ac, threadIdx.x * per + j, r0 + j));
   ShkMP tot;
   ShkMP pre = shk_block_exscan_mp(mine, &tot, mpa, mpb);
   long long f = shk_mp_apply(pre, tile_f[blockIdx.x]);
@@ -1116,7 +1153,7 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
   for (uint32_t j = 0; j < per; j++) {
     const uint32_t r = r0 + j;
     if (r >= nregions) break;
-    const ShkMP m = shk_region_mp(summary, r, nregions, stride);
+    const ShkMP m = shk_tile_mp(ac, threadIdx.x * per + j, r);
     f = shk_mp_apply(m, f);
     fin[r + 1] = (uint64_t)f;
     slots += (uint64_t)m.a;
@@ -1130,10 +1167,7 @@ __global__ void k_region_scan_c(const uint32_t *summary, uint32_t nregions, cons
   // statistics of this tile's regions
   if (stride >= 6)
   for (int z = 0; z < 4; z++) {
-    uint64_t v = 0;
-    for (uint32_t j = 0; j < per; j++)
-      if (r0 + j < nregions) v += summary[(size_t)stride * (r0 + j) + 2 + z];
-    const uint64_t t = shk_block_sum64(v, scratch64);
+    const uint64_t t = shk_block_sum64(stats[z], scratch64);
     if (threadIdx.x == 0 && t) atomicAdd(&counters[z], (unsigned long long)t);
   }
 }

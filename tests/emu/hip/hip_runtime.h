@@ -38,6 +38,8 @@ struct dim3 {
 };
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 v = {x, y, z, w}; return v; }
+struct uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 v = {x, y}; return v; }
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
