@@ -125,7 +125,8 @@ int shk_prepare_chunks(shk_ctx *ctx, const void *text, int text_on_device, uint6
                        const uint64_t *chunk_off, const uint64_t *chunk_len, uint32_t nchunks);
 int shk_count_prepared(shk_ctx *ctx, shk_batch_stats *stats);
 /* Allocates the front end's own buffers and stream now instead of inside the first shk_prepare_chunks (which does it
- * otherwise): for callers that want context set-up and steady state apart, e.g. when timing. Idempotent. */
+ * otherwise), and -- for a context with deNoise rounds -- the records of a deNoise point instead of in the first pass
+ * that needs them: for callers that want context set-up and steady state apart, e.g. when timing. Idempotent. */
 int shk_prepare_reserve(shk_ctx *ctx);
 
 /* Overlapped ingest: start copying host text (pinned memory for full PCIe rate) for a LATER call into one of two
@@ -187,8 +188,8 @@ int shk_stage_words(shk_ctx *ctx, const uint64_t *d_words, uint64_t nwords);
 /* The same from TWO device buffers (a shard's own words, where shk_hash_route_chunks left them, and the words it received):
  * no copy that brings them together first. Neither may lie in the buffer shk_hash_chunks returns (the first partition
  * level writes there): SHK_ERR_ARG. */
-/* Allocates the two send buffers of shk_route_words / shk_hash_route_chunks now instead of inside their first two calls
- * (for callers that keep set-up and steady state apart). Idempotent. */
+/* Allocates the two send buffers of shk_route_words / shk_hash_route_chunks now instead of inside their first two calls,
+ * and the records of a deNoise point (for callers that keep set-up and steady state apart). Idempotent. */
 int shk_route_reserve(shk_ctx *ctx);
 int shk_stage_words_pair(shk_ctx *ctx, const uint64_t *d_words_a, uint64_t nwords_a, const uint64_t *d_words_b, uint64_t nwords_b);
 int shk_stage_summary(shk_ctx *ctx, uint32_t chunk_lo, uint32_t chunk_hi, uint32_t hist_base, uint32_t hist_shift,

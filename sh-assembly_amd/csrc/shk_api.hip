@@ -1542,6 +1542,11 @@ extern "C" int shk_prepare_reserve(shk_ctx *c) {
   if (!c || c->cfg.num_shards > 1) return SHK_ERR_ARG;
   HIPCHK(hipSetDevice(c->dev));
   if (!c->front) { int rc = front_init(c); if (rc) { front_destroy(c); return rc; } }
+  if (c->cfg.num_denoise) {      // (the records of a deNoise point, otherwise allocated by the first pass that needs them)
+    int rc = ensure_chist(c);
+    if (!rc) rc = point_alloc(c);
+    if (rc) return rc;
+  }
   return SHK_OK;
 }
 
@@ -1772,6 +1777,8 @@ extern "C" int shk_route_reserve(shk_ctx *c) {
   HIPCHK(hipSetDevice(c->dev));
   for (int b = 0; b < 2; b++)
     if (!c->d_send[b] && dmalloc(&c->d_send[b], c->cfg.max_batch_keys + 1)) return SHK_ERR_HIP;
+  // (and the records of a deNoise point: a shard's rounds are decided outside the context)
+  { int rc = ensure_chist(c); if (!rc) rc = point_alloc(c); if (rc) return rc; }
   return SHK_OK;
 }
 
